@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the REFERENCE (/root/reference) on CPU.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    cd /tmp && PYTHONPATH=/root/reference:/root/repo PYTHONDONTWRITEBYTECODE=1 \
+        python /root/repo/tools/make_golden.py
+
+Outputs are data only (inputs + the reference's outputs); no reference source is copied.
+`torchvision` is absent here and the reference imports `torchvision.ops.nms` at module import
+(architectures/retinanet.py:5), so a stand-in module is registered first.  The stand-in `nms`
+is OUR oracle restatement (oracle/ref_cpu.py:nms) — the decode-tail fixtures therefore pin the
+reference's wiring around NMS (retinanet.py:297-318), not torchvision's NMS arithmetic, which
+stays "parity unpinned" (SURVEY.md §8c).
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+from oracle import ref_cpu                               # noqa: E402
+import synth                                             # noqa: E402
+
+_tv = types.ModuleType('torchvision')
+_ops = types.ModuleType('torchvision.ops')
+
+
+def _nms_standin(boxes, scores, thr):
+    return torch.from_numpy(ref_cpu.nms(boxes.detach().numpy(), scores.detach().numpy(), thr))
+
+
+_ops.nms = _nms_standin
+_tv.ops = _ops
+sys.modules['torchvision'] = _tv
+sys.modules['torchvision.ops'] = _ops
+
+from architectures import anchors as ref_anchors         # noqa: E402
+from architectures import losses as ref_losses           # noqa: E402
+from architectures import utils as ref_utils             # noqa: E402
+from architectures import retinanet as ref_retinanet     # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+torch.set_grad_enabled(True)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ---------------------------------------------------------------- anchors (a-5)
+def gen_anchors():
+    d = {}
+    effdet = dict(pyramid_levels=[3, 4, 5, 6, 7], strides=[8, 16, 32, 64, 128],
+                  sizes=[2 ** (x + 1) * 1.25 for x in [3, 4, 5, 6, 7]],
+                  ratios=np.array([1, 2]),
+                  scales=np.array([2 ** 0, 2 ** (1.0 / 3.0), 2 ** (2.0 / 3.0)]))
+    cases = [('retina', {}, (256, 256)), ('retina', {}, (512, 512)), ('retina', {}, (640, 640)),
+             ('retina', {}, (100, 130)), ('retina', {}, (33, 77)), ('retina', {}, (8, 8)),
+             ('effdet', effdet, (512, 512)), ('effdet', effdet, (768, 768)),
+             ('effdet', effdet, (96, 160))]
+    names = []
+    for kind, kw, (h, w) in cases:
+        a = ref_anchors.Anchors(**kw)(torch.zeros(1, 3, h, w)).numpy()
+        name = '%s_%dx%d' % (kind, h, w)
+        names.append(name)
+        d[name + '_shape'] = np.array(a.shape)
+        d[name + '_sha256'] = np.array(sha(a))
+        n = a.shape[1]
+        if n <= 13000:
+            d[name + '_full'] = a
+        else:
+            idx = np.unique(np.concatenate([np.arange(0, 64), np.arange(n - 64, n),
+                                            np.random.default_rng(7).integers(0, n, 1024)]))
+            d[name + '_idx'] = idx
+            d[name + '_rows'] = a[0, idx]
+    d['names'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'anchors.npz'), **d)
+    print('anchors:', names)
+
+
+# ---------------------------------------------------------------- loss (a-6, a-7, a-8)
+def run_ref_loss(cls, reg, anchors, ann):
+    cls_t = torch.from_numpy(cls).clone().requires_grad_(True)
+    reg_t = torch.from_numpy(reg).clone().requires_grad_(True)
+    anc_t = torch.from_numpy(anchors)
+    ann_t = torch.from_numpy(ann)
+    fl = ref_losses.FocalLoss()
+    cl, rl = fl(cls_t, reg_t, anc_t, ann_t)
+    # per-loss grads separately (so that a wrong mix of the two is caught)
+    gc_cls, = torch.autograd.grad(cl, cls_t, retain_graph=True, allow_unused=True)
+    gr_reg, = torch.autograd.grad(rl, reg_t, retain_graph=True, allow_unused=True) \
+        if rl.requires_grad else (None,)
+    B, A = cls.shape[0], cls.shape[1]
+    # integer intermediates straight from the reference's own ops (losses.py:64-66,79-80)
+    argmax = np.zeros((B, A), dtype=np.int32)
+    state = np.full((B, A), 3, dtype=np.int8)
+    ioumax = np.zeros((B, A), dtype=np.float32)
+    for j in range(B):
+        ba = ann_t[j]
+        ba = ba[ba[:, 4] != -1]
+        if ba.shape[0] == 0:
+            continue
+        iou = ref_losses.calc_iou(anc_t[0], ba[:, :4])
+        m, am = torch.max(iou, dim=1)
+        st = np.ones(A, dtype=np.int8)
+        st[torch.lt(m, 0.35).numpy()] = 0
+        st[torch.ge(m, 0.45).numpy()] = 2
+        argmax[j] = am.numpy().astype(np.int32)
+        state[j] = st
+        ioumax[j] = m.numpy()
+    return dict(cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(),
+                grad_cls=(gc_cls.numpy() if gc_cls is not None else np.zeros_like(cls)),
+                grad_reg=(gr_reg.numpy() if gr_reg is not None else np.zeros_like(reg)),
+                argmax=argmax, state=state, iou_max=ioumax)
+
+
+def gen_loss():
+    d = {}
+    names = []
+
+    def add(name, cls, reg, anchors, ann):
+        r = run_ref_loss(cls, reg, anchors, ann)
+        names.append(name)
+        d[name + '_cls'] = cls
+        d[name + '_reg'] = reg
+        d[name + '_anchors'] = anchors
+        d[name + '_ann'] = ann
+        for k, v in r.items():
+            d[name + '_' + k] = v
+        print('loss case', name, 'cls', r['cls_loss'], 'reg', r['reg_loss'],
+              'pos', int((r['state'] == 2).sum()), 'ign', int((r['state'] == 1).sum()))
+
+    # (1) 256x256 anchors, C=4, B=3: normal, all-pad image, normal
+    H = W = 256
+    anc = ref_cpu.anchors_for_image(H, W)
+    A = anc.shape[1]
+    cls, reg = synth.synth_head_outputs(3, A, 4, seed=11)
+    ann = synth.synth_annotations(3, H, W, num_real=8, pad_to=16, num_classes=4, seed=12,
+                                  empty_images=(1,))
+    add('c4_256', cls, reg, anc, ann)
+
+    # (2) 64x64, C=80, B=2, with clamp-edge probabilities and tiny boxes (no positives in img 1)
+    H = W = 64
+    anc = ref_cpu.anchors_for_image(H, W)
+    A = anc.shape[1]
+    cls, reg = synth.synth_head_outputs(2, A, 80, seed=21)
+    cls[0, :7, :5] = np.array([0.0, 1.0, 1e-4, 1.0 - 1e-4, 5e-5], dtype=np.float32)
+    ann = synth.synth_annotations(2, H, W, num_real=5, pad_to=8, num_classes=80, seed=22)
+    # image 0: boxes big enough for the 32-px base anchors (jittered copies of real anchors)
+    pick = np.random.default_rng(23).choice(A, 5, replace=False)
+    rows = np.where(ann[0, :, 4] != -1)[0]
+    ann[0, rows, :4] = anc[0, pick] + np.random.default_rng(24).uniform(-2, 2, (5, 4)).astype(np.float32)
+    ann[1, :, :] = -1
+    ann[1, 0] = [10.0, 10.0, 10.5, 10.4, 3]       # w,h < 1 -> clamp(min=1) path never positive
+    ann[1, 3] = [30.0, 31.0, 30.2, 31.9, 79]
+    add('c80_64', cls, reg, anc, ann)
+
+    # (3) hand-made anchors: IoU exactly 0.45 / 0.35 in fp32, argmax ties, degenerate GT
+    anchors = np.array([[[0, 0, 10, 10],        # vs gt0 (0,0,10,4.5): IoU 45/100 = 0.45 -> pos
+                         [20, 0, 30, 10],       # vs gt1 (20,0,30,3.5): IoU 0.35 -> ignore (not <)
+                         [40, 0, 50, 10],       # vs gt2/gt3 identical boxes -> tie -> lowest idx
+                         [60, 0, 70, 10],       # no overlap -> neg
+                         [80, 0, 90, 10],       # gt4 identical -> IoU 1
+                         [100, 0, 110, 10],     # gt5 w<1 (clamp min=1 in target) but IoU>=0.45?
+                         [0, 50, 16, 66],
+                         [0, 50, 16, 66.000004]]], dtype=np.float32)
+    ann = -np.ones((1, 10, 5), dtype=np.float32)
+    ann[0, 0] = [0, 0, 10, 4.5, 1]
+    ann[0, 1] = [-1, -1, -1, -1, -1]
+    ann[0, 2] = [20, 0, 30, 3.5, 0]
+    ann[0, 3] = [40, 0, 50, 10, 2]
+    ann[0, 4] = [40, 0, 50, 10, 3]
+    ann[0, 6] = [80, 0, 90, 10, 0]
+    ann[0, 7] = [100, 0, 100.5, 10, 1]
+    ann[0, 8] = [0, 50, 16, 58, 2]
+    rng = np.random.default_rng(31)
+    cls = rng.uniform(0.001, 0.999, (1, 8, 4)).astype(np.float32)
+    reg = rng.standard_normal((1, 8, 4)).astype(np.float32)
+    add('edges', cls, reg, anchors, ann)
+
+    # (4) EfficientDet-style 6 anchors/cell on 96x160, C=3
+    eff = dict(pyramid_levels=[3, 4, 5, 6, 7], strides=[8, 16, 32, 64, 128],
+               sizes=[2 ** (x + 1) * 1.25 for x in [3, 4, 5, 6, 7]], ratios=[1, 2])
+    anc = ref_cpu.anchors_for_image(96, 160, **eff)
+    A = anc.shape[1]
+    cls, reg = synth.synth_head_outputs(2, A, 3, seed=41)
+    ann = synth.synth_annotations(2, 96, 160, num_real=6, pad_to=6, num_classes=3, seed=42)
+    add('eff_96x160', cls, reg, anc, ann)
+
+    d['names'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'loss.npz'), **d)
+
+
+# ---------------------------------------------------------------- decode / clip / tail (a-9..a-11)
+def gen_decode():
+    d = {}
+    H, W = 96, 128
+    anc = ref_cpu.anchors_for_image(H, W)
+    A = anc.shape[1]
+    rng = np.random.default_rng(51)
+    reg = rng.standard_normal((2, A, 4)).astype(np.float32)
+    reg[:, :, 2:] *= 2.0
+    bt = ref_utils.BBoxTransform()
+    boxes = bt(torch.from_numpy(anc), torch.from_numpy(reg))
+    d['anchors'] = anc
+    d['reg'] = reg
+    d['boxes'] = boxes.numpy().copy()
+    clipped = ref_utils.ClipBoxes()(boxes.clone(), torch.zeros(2, 3, H, W))
+    d['clipped'] = clipped.numpy()
+    d['hw'] = np.array([H, W])
+    np.savez_compressed(os.path.join(OUT, 'decode.npz'), **d)
+    print('decode: boxes', d['boxes'].shape)
+
+
+# ---------------------------------------------------------------- end to end RetinaNet (a-1..a-4)
+def load_synth(model, depth, num_classes, gain):
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    mine = ref_cpu.retinanet_state_shapes(depth, num_classes)
+    assert list(shapes.keys()) == list(mine.keys()), 'state_dict key order differs'
+    assert all(tuple(shapes[k]) == tuple(mine[k]) for k in shapes)
+    sd = synth.synth_state_dict(shapes, seed=0, gain=gain)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return shapes
+
+
+GRAD_KEYS = ['conv1.weight', 'bn1.weight', 'bn1.bias', 'layer1.0.conv1.weight',
+             'layer2.0.downsample.0.weight', 'layer2.0.downsample.1.weight',
+             'layer3.1.bn2.bias', 'layer4.1.conv2.weight', 'fpn.P5_1.weight', 'fpn.P3_2.bias',
+             'fpn.P6.weight', 'fpn.P7_2.bias', 'regressionModel.conv1.weight',
+             'regressionModel.output.bias', 'classificationModel.conv4.bias',
+             'classificationModel.output.weight', 'classificationModel.output.bias']
+
+
+def gen_e2e(depth, H, W, B, num_classes, tag, gain):
+    torch.manual_seed(0)
+    model = ref_retinanet.retinanet(depth, num_classes=num_classes)
+    shapes = load_synth(model, depth, num_classes, gain)
+    model.train()
+    model.freeze_bn()
+    img = synth.synth_images(B, H, W, seed=1)
+    ann = synth.synth_annotations(B, H, W, num_real=8, pad_to=16, num_classes=num_classes, seed=2)
+    img_t, ann_t = torch.from_numpy(img), torch.from_numpy(ann)
+    cls, reg = model(img_t, return_head=True)
+    cl, rl = model(img_t, ann_t)
+    loss = cl.mean() + rl.mean()                                  # train.py:312-314
+    model.zero_grad()
+    loss.backward()
+    grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters()}
+    d = dict(cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(),
+             depth=np.array(depth), hw=np.array([H, W]), batch=np.array(B),
+             num_classes=np.array(num_classes), gain=np.array(gain))
+    A = cls.shape[1]
+    idx = np.arange(0, A, 37)
+    d['head_idx'] = idx
+    d['cls_rows'] = cls.detach().numpy()[:, idx, :]
+    d['reg_rows'] = reg.detach().numpy()[:, idx, :]
+    d['cls_sum'] = np.array(cls.detach().double().sum().item())
+    d['reg_abs_sum'] = np.array(reg.detach().double().abs().sum().item())
+    for k in GRAD_KEYS:
+        if k in grads:
+            g = grads[k]
+            d['grad/' + k + '/norm'] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            flat = g.reshape(-1)
+            sel = np.linspace(0, flat.size - 1, min(flat.size, 512)).astype(np.int64)
+            d['grad/' + k + '/idx'] = sel
+            d['grad/' + k + '/val'] = flat[sel]
+    d['grad_global_norm'] = np.array(np.sqrt(sum((g.astype(np.float64) ** 2).sum()
+                                                 for g in grads.values())))
+    d['state_keys'] = np.array(list(shapes.keys()))
+    d['state_shapes'] = np.array([','.join(map(str, shapes[k])) for k in shapes])
+    # decode tail on image 0 (B must be 1, retinanet.py:302)
+    model.eval()
+    with torch.no_grad():
+        s, c, b = model(img_t[:1], return_loss=False)
+    d['det_scores'] = s.numpy()
+    d['det_classes'] = c.numpy()
+    d['det_boxes'] = b.numpy()
+    np.savez_compressed(os.path.join(OUT, 'e2e_%s.npz' % tag), **d)
+    print('e2e', tag, 'cls', cl.item(), 'reg', rl.item(), 'dets', s.shape,
+          'gnorm', d['grad_global_norm'])
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['anchors', 'loss', 'decode', 'e2e']
+    if 'anchors' in which:
+        gen_anchors()
+    if 'loss' in which:
+        gen_loss()
+    if 'decode' in which:
+        gen_decode()
+    if 'e2e' in which:
+        gen_e2e(18, 256, 256, 2, 80, 'r18_256', 0.87)     # BASELINE.json configs[0]
+        gen_e2e(50, 128, 160, 1, 20, 'r50_128x160', 0.78) # bottleneck path, ragged H != W
