@@ -1,0 +1,108 @@
+/* mi355det — C ABI of the convolution engine (gfx950 MFMA implicit GEMM, NHWC bf16).
+ *
+ * Replaces the ATen/cuDNN calls behind the reference's `nn.Conv2d` + `BatchNorm2d(eval)` +
+ * ReLU / residual-add / sigmoid / nearest-upsample-add chains:
+ *   architectures/retinanet.py:48-69 (FPN), :92-115 / :142-178 (heads), :272-287 (backbone),
+ *   architectures/utils_resnet.py:25-41, :60-80 (blocks).
+ * The reference has no FFI here (pure Python on torch): see INTEGRATION.md for the binding.
+ *
+ * One generic "gather conv" covers forward convolution (any kernel/stride/pad), data-gradient
+ * (stride 1: flipped taps; stride 2: one problem per output-parity class) and the five pyramid
+ * levels of the shared-weight heads as ONE grouped launch.
+ */
+#ifndef MI355DET_CONV_H_
+#define MI355DET_CONV_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_CONV_MAX_PROBLEMS 5
+
+/* One problem of a grouped launch.  Output row m = (n*P + p)*Q + q.
+ * Tap (i,j), i < TR, j < TS reads input pixel (p*sh + dh0 + i*dhs, q*sw + dw0 + j*dws) (zeros
+ * outside [0,H)x[0,W)) and weight tap (r0 + i*rs)*S + (s0 + j*ss). */
+typedef struct Mi355ConvProblem {
+    const void* in;      /* bf16 NHWC [N][H][W][C] */
+    void* out;           /* bf16 or fp32, element offset of (n,p,q,k) =
+                            n*out_sN + (p*out_mh+out_oh)*out_sH + (q*out_mw+out_ow)*out_sW + k */
+    const void* addend;  /* optional bf16, element offset n*add_sN + (p>>add_shift)*add_sH +
+                            (q>>add_shift)*add_sW + k ; added before the activation */
+    const void* mask;    /* optional bf16, same indexing as out: result *= (mask > 0) */
+    int32_t N, H, W, C;
+    int32_t P, Q;
+    int32_t sh, sw;
+    int32_t TR, TS, dh0, dhs, dw0, dws;
+    int32_t r0, rs, s0, ss, S;
+    int32_t out_mh, out_oh, out_mw, out_ow;
+    int64_t out_sN, out_sH, out_sW;
+    int64_t add_sN, add_sH, add_sW;
+    int32_t add_shift;
+    int32_t reserved;
+} Mi355ConvProblem;
+
+typedef struct Mi355ConvLaunch {
+    Mi355ConvProblem prob[MI355_CONV_MAX_PROBLEMS];
+    int32_t nprob;
+    int32_t K;            /* output channels */
+    const void* weight;   /* bf16 [K][T][C] (T = full tap count, C = prob.C), reduction-contiguous */
+    int32_t T;            /* taps per weight row */
+    int32_t act;          /* 0 none, 1 relu, 2 sigmoid */
+    const float* bias;    /* optional fp32 [K] (conv bias or folded frozen-BN shift) */
+    int32_t out_f32;      /* 0: bf16 out, 1: fp32 out */
+    int32_t reserved;
+} Mi355ConvLaunch;
+
+/* out = act( gatherconv(in, weight) + bias + addend ) * (mask > 0) for every problem. */
+int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream);
+
+/* Weight gradient of the same gather conv, grouped over problems that share the weight:
+ *   dw[k][t][c] += sum_m dy[m][k] * in[m @ tap t][c]        (fp32 atomics; zero dw first)
+ * Problem fields used: in, N,H,W,C, P,Q, sh,sw, TR,TS,dh0,dhs,dw0,dws, r0,rs,s0,ss,S;
+ * `out` holds the dense bf16 dy [N*P*Q][K] of that problem. dw is fp32 [K][T][C]. */
+int mi355_conv_wgrad(const Mi355ConvLaunch* launch, float* dw, int split_rows, void* stream);
+
+/* ---- elementwise / layout helpers of the conv path --------------------------------------- */
+/* fp32 NCHW [N][C][H][W] -> bf16 NHWC [N][H][W][Cpad] (channels >= C zero). */
+int mi355_nchw_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int W, int Cpad,
+                            void* stream);
+/* Weight preparation: fp32 [K][C][R][S] with arbitrary element strides (sk,sc,sr,ss) ->
+ *   w_fwd bf16 [K][R*S][Cpad]  = w * scale[k]          (forward operand)
+ *   w_dgr bf16 [C][R*S][K]     = w * scale[k]          (dgrad operand), either may be NULL.
+ * scale (fp32 [K], may be NULL = 1) is the folded frozen-BN gamma/sqrt(var+eps). */
+int mi355_prep_weight(const float* w, int64_t sk, int64_t sc, int64_t sr, int64_t ss, int K, int C,
+                      int R, int S, int Cpad, const float* scale, void* w_fwd, void* w_dgr,
+                      void* stream);
+/* Frozen-BN fold: scale = gamma / sqrt(var + eps), shift = beta - mean * scale  (fp32 [K]). */
+int mi355_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                  float eps, int K, float* scale, float* shift, void* stream);
+/* Column sums: out[k] (+)= sum_m g[m][k], g bf16 [M][K] (bias / BN-beta gradients). */
+int mi355_colsum_bf16(const void* g, int64_t M, int K, float* out, void* stream);
+/* Finish a conv layer's parameter gradients from the raw wgrad G = X^T dY (fp32 [K][T][Cpad]):
+ *   dW[k][c][r][s] (strides sk,sc,sr,ss; fp32) (+)= G[k][t][c] * scale[k]       (c < C)
+ *   if gamma given (frozen BN, retinanet.py:266-270 keeps gamma/beta trainable):
+ *     dgamma[k] (+)= invstd[k] * ( sum_{t,c} W[k][c][r][s]*G[k][t][c] - mean[k]*colsum[k] )
+ *     dbeta[k]  (+)= colsum[k]
+ * accumulate != 0 adds to the existing gradient buffers. */
+int mi355_conv_param_grads(const float* G, const float* w, int64_t sk, int64_t sc, int64_t sr,
+                           int64_t ss, int K, int C, int R, int S, int Cpad, const float* scale,
+                           const float* colsum, const float* mean, const float* var, float eps,
+                           float* dW, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* MaxPool 3x3 s2 p1 (retinanet.py:188) NHWC bf16; idx int8 [N][P][Q][C] = argmax window slot. */
+int mi355_maxpool3x3s2_fwd(const void* in, void* out, int8_t* idx, int N, int H, int W, int C,
+                           void* stream);
+int mi355_maxpool3x3s2_bwd(const void* gout, const int8_t* idx, void* gin, const void* relu_mask,
+                           int N, int H, int W, int C, void* stream);
+/* Nearest-2x upsample backward: dst[n][p][q][c] (+)= sum of the 2x2 children of src
+ * (src [N][H][W][C], dst [N][ceil(H/2)][ceil(W/2)][C], bf16). */
+int mi355_sumpool2x2_bf16(const void* src, void* dst, int N, int H, int W, int C, int accumulate,
+                          void* stream);
+/* y = x * (ref > 0) elementwise, bf16 (ReLU backward with the saved output). n elements. */
+int mi355_relu_mask_bf16(const void* x, const void* ref, void* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355DET_CONV_H_ */

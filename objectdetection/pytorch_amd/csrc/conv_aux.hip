@@ -1,0 +1,342 @@
+// HBM-bound helpers around the MFMA conv kernels (gfx950): layout conversion, weight
+// preparation (frozen-BN fold + bf16 shadow copies), parameter-gradient finishing, max-pool,
+// nearest-upsample backward, ReLU mask, column sums.  All activation traffic is 16 B per lane.
+#include "conv_common.h"
+
+using namespace mi355;
+
+// ----------------------------------------------------------------------- NCHW fp32 -> NHWC bf16
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, unsigned short* __restrict__ out,
+                                    long long npix_total, int C, long long HW, int Cpad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // pixel index (n, hw)
+    if (i >= npix_total) return;
+    const long long n = i / HW, hw = i - n * HW;
+    const float* src = in + n * C * HW + hw;
+    unsigned short* dst = out + i * Cpad;
+    for (int c0 = 0; c0 < Cpad; c0 += 8) {
+        s8v o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            o[e] = (short)(c < C ? f32_to_bf16_rn(src[c * HW]) : (unsigned short)0);
+        }
+        *reinterpret_cast<s8v*>(dst + c0) = o;
+    }
+}
+
+extern "C" int mi355_nchw_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int W,
+                                       int Cpad, void* stream) {
+    MI355_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % 8 == 0,
+                  "nchw_to_nhwc: bad args");
+    const long long npix = (long long)N * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)cdiv(npix, 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, (unsigned short*)out, npix, C, (long long)H * W, Cpad);
+    return check_launch("nchw_to_nhwc_kernel");
+}
+
+// ----------------------------------------------------------------------- frozen-BN fold
+__global__ void bn_fold_kernel(const float* g, const float* b, const float* m, const float* v,
+                               float eps, int K, float* scale, float* shift) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float s = g[k] / sqrtf(v[k] + eps);
+    scale[k] = s;
+    shift[k] = b[k] - m[k] * s;
+}
+
+extern "C" int mi355_bn_fold(const float* gamma, const float* beta, const float* mean,
+                             const float* var, float eps, int K, float* scale, float* shift,
+                             void* stream) {
+    MI355_REQUIRE(gamma && beta && mean && var && scale && shift && K > 0, "bn_fold: bad args");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream,
+                       gamma, beta, mean, var, eps, K, scale, shift);
+    return check_launch("bn_fold_kernel");
+}
+
+// ----------------------------------------------------------------------- weight preparation
+// One block = one (rs, 32 k, 32 c) tile: coalesced fp32 reads, LDS transpose, bf16 writes of
+// both operand layouts.
+__global__ __launch_bounds__(256) void prep_weight_kernel(
+    const float* __restrict__ w, long long sk, long long sc, long long sr, long long ss, int K, int C,
+    int R, int S, int Cpad, const float* __restrict__ scale, unsigned short* __restrict__ w_fwd,
+    unsigned short* __restrict__ w_dgr, int Kpad) {
+    __shared__ float tile[32][33];
+    const int rs = blockIdx.z, r = rs / S, s = rs - r * S;
+    const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const int T = R * S;
+    for (int j = ty; j < 32; j += 8) {
+        const int k = k0 + j, c = c0 + tx;
+        float v = 0.0f;
+        if (k < K && c < C) v = w[k * sk + c * sc + r * sr + s * ss] * (scale ? scale[k] : 1.0f);
+        tile[j][tx] = v;
+        if (w_fwd && k < K && c < Cpad) w_fwd[((long long)k * T + rs) * Cpad + c] = f32_to_bf16_rn(v);
+    }
+    __syncthreads();
+    if (w_dgr) {
+        for (int j = ty; j < 32; j += 8) {
+            const int c = c0 + j, k = k0 + tx;
+            if (c < C && k < Kpad) w_dgr[((long long)c * T + rs) * Kpad + k] = f32_to_bf16_rn(tile[tx][j]);
+        }
+    }
+}
+
+extern "C" int mi355_prep_weight(const float* w, int64_t sk, int64_t sc, int64_t sr, int64_t ss, int K,
+                                 int C, int R, int S, int Cpad, const float* scale, void* w_fwd,
+                                 void* w_dgr, void* stream) {
+    MI355_REQUIRE(w && K > 0 && C > 0 && R > 0 && S > 0 && Cpad >= C && Cpad % 8 == 0, "prep_weight: bad args");
+    const int Kpad = (K + 7) / 8 * 8;
+    dim3 grid((unsigned)cdiv(Cpad, 32), (unsigned)cdiv(Kpad, 32), (unsigned)(R * S));
+    hipLaunchKernelGGL(prep_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, (long long)sk,
+                       (long long)sc, (long long)sr, (long long)ss, K, C, R, S, Cpad, scale,
+                       (unsigned short*)w_fwd, (unsigned short*)w_dgr, Kpad);
+    return check_launch("prep_weight_kernel");
+}
+
+// ----------------------------------------------------------------------- column sums
+__global__ void colsum_kernel(const unsigned short* __restrict__ g, long long M, int K, int rsplit,
+                              float* __restrict__ out) {
+    const int k8n = K >> 3;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)k8n * rsplit) return;
+    const int k8 = (int)(t % k8n);
+    const int rs = (int)(t / k8n);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long m = rs; m < M; m += rsplit) {
+        const s8v v = *reinterpret_cast<const s8v*>(g + m * K + k8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf16_to_f32((unsigned short)v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(out + k8 * 8 + e, acc[e]);
+}
+
+extern "C" int mi355_colsum_bf16(const void* g, int64_t M, int K, float* out, void* stream) {
+    MI355_REQUIRE(g && out && M > 0 && K > 0 && K % 8 == 0, "colsum: K must be a multiple of 8");
+    const int k8n = K / 8;
+    long long rsplit = 65536 / k8n;
+    if (rsplit < 1) rsplit = 1;
+    if (rsplit > M) rsplit = M;
+    const long long threads = (long long)k8n * rsplit;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const unsigned short*)g, (long long)M, K, (int)rsplit, out);
+    return check_launch("colsum_kernel");
+}
+
+// ----------------------------------------------------------------------- parameter gradients
+// One block per output channel k: dW = G*scale[k]; dgamma/dbeta of the folded frozen BN.
+__global__ __launch_bounds__(256) void conv_param_grads_kernel(
+    const float* __restrict__ G, const float* __restrict__ w, long long sk, long long sc, long long sr,
+    long long ss, int C, int R, int S, int Cpad, const float* __restrict__ scale,
+    const float* __restrict__ colsum, const float* __restrict__ mean, const float* __restrict__ var,
+    float eps, float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    int accumulate) {
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int T = R * S;
+    const float sck = scale ? scale[k] : 1.0f;
+    float dot = 0.0f;
+    const int total = T * Cpad;
+    for (int i = tid; i < total; i += 256) {
+        const int t = i / Cpad, c = i - t * Cpad;
+        if (c >= C) continue;
+        const int r = t / S, s = t - r * S;
+        const float gv = G[(long long)k * total + i];
+        const long long wo = k * sk + c * sc + r * sr + s * ss;
+        if (dgamma) dot += w[wo] * gv;
+        const float d = gv * sck;
+        dW[wo] = accumulate ? dW[wo] + d : d;
+    }
+    if (dgamma || dbeta) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = dot;
+        __syncthreads();
+        if (tid == 0) {
+            const float cs = colsum[k];
+            if (dgamma) {
+                const float invstd = 1.0f / sqrtf(var[k] + eps);
+                const float dg = invstd * ((red[0] + red[1] + red[2] + red[3]) - mean[k] * cs);
+                dgamma[k] = accumulate ? dgamma[k] + dg : dg;
+            }
+            if (dbeta) dbeta[k] = accumulate ? dbeta[k] + cs : cs;
+        }
+    }
+}
+
+extern "C" int mi355_conv_param_grads(const float* G, const float* w, int64_t sk, int64_t sc,
+                                      int64_t sr, int64_t ss, int K, int C, int R, int S, int Cpad,
+                                      const float* scale, const float* colsum, const float* mean,
+                                      const float* var, float eps, float* dW, float* dgamma,
+                                      float* dbeta, int accumulate, void* stream) {
+    MI355_REQUIRE(G && w && dW && K > 0 && C > 0 && R > 0 && S > 0 && Cpad >= C, "conv_param_grads: bad args");
+    MI355_REQUIRE(!(dgamma || dbeta) || colsum, "conv_param_grads: colsum needed for dgamma/dbeta");
+    MI355_REQUIRE(!dgamma || (mean && var), "conv_param_grads: mean/var needed for dgamma");
+    hipLaunchKernelGGL(conv_param_grads_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, G, w,
+                       (long long)sk, (long long)sc, (long long)sr, (long long)ss, C, R, S, Cpad, scale,
+                       colsum, mean, var, eps, dW, dgamma, dbeta, accumulate);
+    return check_launch("conv_param_grads_kernel");
+}
+
+// ----------------------------------------------------------------------- max-pool 3x3 s2 p1
+__global__ void maxpool_fwd_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
+                                   signed char* __restrict__ idx, int N, int H, int W, int C, int P, int Q) {
+    const int c8n = C >> 3;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * P * Q * c8n;
+    if (t >= total) return;
+    const int c8 = (int)(t % c8n);
+    long long r = t / c8n;
+    const int q = (int)(r % Q);  r /= Q;
+    const int p = (int)(r % P);
+    const int n = (int)(r / P);
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int h = 2 * p - 1 + a;
+        if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int w = 2 * q - 1 + b;
+            if ((unsigned)w >= (unsigned)W) continue;
+            const s8v v = *reinterpret_cast<const s8v*>(in + (((long long)n * H + h) * W + w) * C + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = bf16_to_f32((unsigned short)v[e]);
+                if (f > best[e] || bi[e] < 0) { best[e] = f; bi[e] = a * 3 + b; }   // first max wins
+            }
+        }
+    }
+    s8v o;
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e] = (short)f32_to_bf16_rn(best[e]);
+        packed |= (unsigned long long)(bi[e] & 0xff) << (8 * e);
+    }
+    *reinterpret_cast<s8v*>(out + t * 8) = o;
+    *reinterpret_cast<unsigned long long*>(idx + t * 8) = packed;
+}
+
+extern "C" int mi355_maxpool3x3s2_fwd(const void* in, void* out, int8_t* idx, int N, int H, int W, int C,
+                                      void* stream) {
+    MI355_REQUIRE(in && out && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_fwd: bad args");
+    const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * P * Q * (C / 8);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)in, (unsigned short*)out, (signed char*)idx, N, H, W, C, P, Q);
+    return check_launch("maxpool_fwd_kernel");
+}
+
+__global__ void maxpool_bwd_kernel(const unsigned short* __restrict__ gout, const signed char* __restrict__ idx,
+                                   unsigned short* __restrict__ gin, const unsigned short* __restrict__ relu_mask,
+                                   int N, int H, int W, int C, int P, int Q) {
+    const int c8n = C >> 3;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * H * W * c8n;
+    if (t >= total) return;
+    const int c8 = (int)(t % c8n);
+    long long r = t / c8n;
+    const int w = (int)(r % W);  r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int p_lo = max(0, h / 2), p_hi = min(P - 1, (h + 1) / 2);       // 2p-1 <= h <= 2p+1
+    const int q_lo = max(0, w / 2), q_hi = min(Q - 1, (w + 1) / 2);
+    for (int p = p_lo; p <= p_hi; ++p)
+        for (int q = q_lo; q <= q_hi; ++q) {
+            const int slot = (h - (2 * p - 1)) * 3 + (w - (2 * q - 1));
+            const long long o = (((long long)n * P + p) * Q + q) * C + c8 * 8;
+            const unsigned long long pk = *reinterpret_cast<const unsigned long long*>(idx + o);
+            const s8v g = *reinterpret_cast<const s8v*>(gout + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if ((int)((pk >> (8 * e)) & 0xff) == slot) acc[e] += bf16_to_f32((unsigned short)g[e]);
+        }
+    if (relu_mask) {
+        const s8v m = *reinterpret_cast<const s8v*>(relu_mask + t * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (!(bf16_to_f32((unsigned short)m[e]) > 0.0f)) acc[e] = 0.0f;
+    }
+    s8v o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(acc[e]);
+    *reinterpret_cast<s8v*>(gin + t * 8) = o;
+}
+
+extern "C" int mi355_maxpool3x3s2_bwd(const void* gout, const int8_t* idx, void* gin, const void* relu_mask,
+                                      int N, int H, int W, int C, void* stream) {
+    MI355_REQUIRE(gout && idx && gin && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_bwd: bad args");
+    const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * H * W * (C / 8);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)gout, (const signed char*)idx, (unsigned short*)gin,
+                       (const unsigned short*)relu_mask, N, H, W, C, P, Q);
+    return check_launch("maxpool_bwd_kernel");
+}
+
+// ----------------------------------------------------------------------- nearest-2x upsample backward
+__global__ void sumpool2x2_kernel(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst,
+                                  int N, int H, int W, int C, int P, int Q, int accumulate) {
+    const int c8n = C >> 3;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * P * Q * c8n;
+    if (t >= total) return;
+    const int c8 = (int)(t % c8n);
+    long long r = t / c8n;
+    const int q = (int)(r % Q);  r /= Q;
+    const int p = (int)(r % P);
+    const int n = (int)(r / P);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (accumulate) {
+        const s8v d = *reinterpret_cast<const s8v*>(dst + t * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bf16_to_f32((unsigned short)d[e]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int h = 2 * p + a, w = 2 * q + b;
+            if (h >= H || w >= W) continue;
+            const s8v v = *reinterpret_cast<const s8v*>(src + (((long long)n * H + h) * W + w) * C + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf16_to_f32((unsigned short)v[e]);
+        }
+    s8v o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(acc[e]);
+    *reinterpret_cast<s8v*>(dst + t * 8) = o;
+}
+
+extern "C" int mi355_sumpool2x2_bf16(const void* src, void* dst, int N, int H, int W, int C, int accumulate,
+                                     void* stream) {
+    MI355_REQUIRE(src && dst && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "sumpool2x2: bad args");
+    const int P = (H + 1) / 2, Q = (W + 1) / 2;
+    const long long total = (long long)N * P * Q * (C / 8);
+    hipLaunchKernelGGL(sumpool2x2_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, (unsigned short*)dst, N, H, W, C, P, Q, accumulate);
+    return check_launch("sumpool2x2_kernel");
+}
+
+// ----------------------------------------------------------------------- ReLU mask
+__global__ void relu_mask_kernel(const s8v* __restrict__ x, const s8v* __restrict__ ref, s8v* __restrict__ y,
+                                 long long n8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const s8v a = x[i], r = ref[i];
+    s8v o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = bf16_to_f32((unsigned short)r[e]) > 0.0f ? a[e] : (short)0;
+    y[i] = o;
+}
+
+extern "C" int mi355_relu_mask_bf16(const void* x, const void* ref, void* y, int64_t n, void* stream) {
+    MI355_REQUIRE(x && ref && y && n > 0 && n % 8 == 0, "relu_mask: n must be a multiple of 8");
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)cdiv(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const s8v*)x, (const s8v*)ref, (s8v*)y, (long long)(n / 8));
+    return check_launch("relu_mask_kernel");
+}

@@ -1,0 +1,40 @@
+// Device-side helpers shared by the MFMA conv kernels (gfx950).
+#pragma once
+#include "common.h"
+#include "mi355det_conv.h"
+
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+
+namespace mi355 {
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short v) {
+    return __uint_as_float(((unsigned int)v) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_rn(float f) {
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+
+// Bijective XCD-aware remap (cdna_hip_programming.md T1): blocks that share an XCD (bid % 8)
+// get a contiguous range of tile ids, so that neighbouring tiles reuse the XCD's L2.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + (bid >> 3);
+}
+
+// Buffer resource over [base, base+bytes): out-of-range 16-B requests return zeros, which is
+// how conv padding / tile tails are produced (probed on hardware: tools/probe_gfx950.hip [3]).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* p = (void*)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+constexpr unsigned OOB_OFFSET = 0x80000000u;
+
+}  // namespace mi355

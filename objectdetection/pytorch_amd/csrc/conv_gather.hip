@@ -1,0 +1,337 @@
+// Grouped "gather conv" on gfx950 MFMA: forward convolution, data gradient and the five-level
+// shared-weight head convs as one implicit-GEMM kernel.
+//
+//   out[m][k] = act( sum_{tap,c} in[m @ tap][c] * w[k][tap][c] + bias[k] + addend[m][k] ) * (mask>0)
+//
+// GEMM view: M = N*P*Q output pixels, N = K output channels, reduction = taps x C, both operands
+// reduction-contiguous (NHWC activations, [K][tap][C] weights) = the natural bf16 MFMA layout.
+// Tile 128x128x64, 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 accumulators.
+// Operands are staged global->LDS with buffer_load_dwordx4 ... lds (LDS-DMA, no VGPR round
+// trip); the per-lane SOURCE address does the im2col gather, out-of-range requests return
+// zeros (padding / tails); the LDS image is lane-linear with the XOR swizzle applied on the
+// source chunk and on the ds_read_b128 address (conflict-free for the b128 lane groups).
+// Double-buffered: the DMA of k-step t+1 is in flight while k-step t runs on the matrix cores.
+// Epilogue goes through LDS so that bias/addend/mask reads and the output stores are 16-B
+// coalesced rows.
+//
+// Replaces: nn.Conv2d (+ frozen BatchNorm2d, ReLU, residual add, sigmoid, upsample-add) call
+// chains of architectures/retinanet.py:48-69, :92-115, :142-178, :272-287 and
+// architectures/utils_resnet.py:25-41, :60-80, and their autograd data-gradients.
+#include "conv_common.h"
+
+using namespace mi355;
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;          // 32 KiB
+constexpr int EPI_LD = BN + 4;                           // fp32 row stride of the epilogue image
+constexpr int LDS_BYTES = (2 * STAGE_BYTES > BM * EPI_LD * 4) ? 2 * STAGE_BYTES : BM * EPI_LD * 4;
+
+struct ProbDev {
+    const unsigned short* in;
+    void* out;
+    const unsigned short* addend;
+    const unsigned short* mask;
+    int N, H, W, C, P, Q, sh, sw;
+    int TR, TS, dh0, dhs, dw0, dws;
+    int r0, rs, s0, ss, S;
+    int out_mh, out_oh, out_mw, out_ow;
+    long long out_sN, out_sH, out_sW;
+    long long add_sN, add_sH, add_sW;
+    int add_shift;
+    int tile_begin;
+    int M;
+    int in_bytes;
+};
+
+struct LaunchDev {
+    ProbDev p[MI355_CONV_MAX_PROBLEMS];
+    const unsigned short* w;
+    const float* bias;
+    int nprob, K, T, act, out_f32, n_tiles, w_bytes;
+};
+
+__device__ __forceinline__ float activate(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.0f);
+    if (act == 2) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+template <bool FLAT>
+__global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDev L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ long long s_outoff[BM];
+    __shared__ long long s_addoff[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m_tile = tile / L.n_tiles, n_tile = tile - m_tile * L.n_tiles;
+
+    // ---- select the problem of this tile (scalar selects over the by-value descriptors)
+    ProbDev P = L.p[0];
+#pragma unroll
+    for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
+        if (i < L.nprob && m_tile >= L.p[i].tile_begin) P = L.p[i];
+    const int m0 = (m_tile - P.tile_begin) * BM;
+    const int n0 = n_tile * BN;
+    const int PQ = P.P * P.Q;
+
+    // ---- per-row output / addend offsets (used by the epilogue)
+    if (tid < BM) {
+        const int m = m0 + tid;
+        long long oo = -1, ao = -1;
+        if (m < P.M) {
+            const int n = m / PQ, rem = m - n * PQ, p = rem / P.Q, q = rem - p * P.Q;
+            oo = n * P.out_sN + (long long)(p * P.out_mh + P.out_oh) * P.out_sH +
+                 (long long)(q * P.out_mw + P.out_ow) * P.out_sW;
+            ao = n * P.add_sN + (long long)(p >> P.add_shift) * P.add_sH +
+                 (long long)(q >> P.add_shift) * P.add_sW;
+        }
+        s_outoff[tid] = oo;
+        s_addoff[tid] = ao;
+    }
+
+    // ---- staging geometry: thread owns LDS slot (row = tid/8 + 32 i, slot = tid%8), i = 0..3,
+    //      and loads the global chunk kc = slot ^ (row & 7) into it.
+    const int slot = tid & 7;
+    const int kc = slot ^ ((tid >> 3) & 7);
+    int a_base[4], a_ih0[4], a_iw0[4];
+    unsigned b_rowoff[4];
+    const int wrow = L.T * P.C;                       // elements per weight row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int m = m0 + row;
+        if (m < P.M) {
+            const int n = m / PQ, rem = m - n * PQ, p = rem / P.Q, q = rem - p * P.Q;
+            a_ih0[i] = p * P.sh + P.dh0;
+            a_iw0[i] = q * P.sw + P.dw0;
+            a_base[i] = ((n * P.H + a_ih0[i]) * P.W + a_iw0[i]) * P.C;
+        } else {
+            a_ih0[i] = -0x40000000;                   // never valid
+            a_iw0[i] = 0;
+            a_base[i] = 0;
+        }
+        const int nn = n0 + row;
+        b_rowoff[i] = nn < L.K ? (unsigned)(nn * wrow) * 2u : OOB_OFFSET;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(P.in, (unsigned)P.in_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(L.w, (unsigned)L.w_bytes);
+
+    const int ntaps = P.TR * P.TS;
+    const int cpt = P.C >> 3;                          // 16-B chunks per tap
+    const int ksteps = FLAT ? (ntaps * cpt + 7) / 8 : ntaps * (P.C / BK);
+    const int csteps = FLAT ? 1 : P.C / BK;
+
+    auto issue = [&](int ks, int buf) {
+        unsigned char* sa = smem + buf * STAGE_BYTES;
+        unsigned char* sb = sa + BM * BK * 2;
+        int ti, tj, c0;
+        bool tap_ok = true;
+        if (FLAT) {
+            const int J = ks * 8 + kc;
+            const int tap = J / cpt;
+            c0 = (J - tap * cpt) * 8;
+            ti = tap / P.TS;
+            tj = tap - ti * P.TS;
+            tap_ok = tap < ntaps;
+        } else {
+            const int tap = ks / csteps;               // wave-uniform
+            c0 = (ks - tap * csteps) * BK + kc * 8;
+            ti = tap / P.TS;
+            tj = tap - ti * P.TS;
+        }
+        const int dh = ti * P.dhs, dw = tj * P.dws;
+        const int a_delta = (dh * P.W + dw) * P.C + c0;
+        const unsigned b_delta = (unsigned)(((P.r0 + ti * P.rs) * P.S + (P.s0 + tj * P.ss)) * P.C + c0) * 2u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = tap_ok && (unsigned)(a_ih0[i] + dh) < (unsigned)P.H &&
+                            (unsigned)(a_iw0[i] + dw) < (unsigned)P.W;
+            const unsigned off = ok ? (unsigned)(a_base[i] + a_delta) * 2u : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (LDS_PTR(void))(sa + (i * 256 + wv * 64) * 16),
+                                                     16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned off = (tap_ok && b_rowoff[i] != OOB_OFFSET) ? b_rowoff[i] + b_delta : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (LDS_PTR(void))(sb + (i * 256 + wv * 64) * 16),
+                                                     16, off, 0, 0, 0);
+        }
+    };
+
+    f4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wv >> 1, wn = wv & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    // ds_read_b128 byte offsets of this lane's fragments inside a stage (row r, chunk c):
+    //   r*128 + ((c ^ (r & 7)) << 4); r & 7 == fr & 7 for every 16-row tile.
+    const int a_rd = (wm * 64 + fr) * 128;
+    const int b_rd = BM * BK * 2 + (wn * 64 + fr) * 128;
+    const int sw0 = ((fq) ^ (fr & 7)) << 4;           // k-sub 0: chunk fq
+    const int sw1 = ((4 + fq) ^ (fr & 7)) << 4;       // k-sub 1: chunk 4 + fq
+
+    if (ksteps > 0) issue(0, 0);
+    __syncthreads();
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < ksteps) issue(ks + 1, buf ^ 1);
+        const unsigned char* st = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int sw = sub ? sw1 : sw0;
+            s8v af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *reinterpret_cast<const s8v*>(st + a_rd + t * 16 * 128 + sw);
+                bf[t] = *reinterpret_cast<const s8v*>(st + b_rd + t * 16 * 128 + sw);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> coalesced rows
+    float* epi = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                epi[(wm * 64 + i * 16 + fq * 4 + r) * EPI_LD + wn * 64 + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+
+    const int cchunk = tid & 15;
+    const int col = cchunk * 8;
+    const int k0 = n0 + col;
+    if (k0 < L.K) {
+        const int nvalid = min(8, L.K - k0);
+        float bias[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias[e] = (L.bias && e < nvalid) ? L.bias[k0 + e] : 0.0f;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int row = pass * 16 + (tid >> 4);
+            const long long oo = s_outoff[row];
+            if (oo < 0) continue;
+            const f4v v0 = *reinterpret_cast<const f4v*>(epi + row * EPI_LD + col);
+            const f4v v1 = *reinterpret_cast<const f4v*>(epi + row * EPI_LD + col + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias[e];
+            if (P.addend) {
+                const unsigned short* ap = P.addend + s_addoff[row] + k0;
+                if (nvalid == 8) {
+                    const s8v a = *reinterpret_cast<const s8v*>(ap);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((unsigned short)a[e]);
+                } else {
+                    for (int e = 0; e < nvalid; ++e) v[e] += bf16_to_f32(ap[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = activate(v[e], L.act);
+            if (P.mask) {
+                const unsigned short* mp = P.mask + oo + k0;
+                if (nvalid == 8) {
+                    const s8v a = *reinterpret_cast<const s8v*>(mp);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((unsigned short)a[e]) > 0.0f ? v[e] : 0.0f;
+                } else {
+                    for (int e = 0; e < nvalid; ++e) v[e] = bf16_to_f32(mp[e]) > 0.0f ? v[e] : 0.0f;
+                }
+            }
+            if (L.out_f32) {
+                float* op = reinterpret_cast<float*>(P.out) + oo + k0;
+                if (nvalid == 8) {
+                    *reinterpret_cast<f4v*>(op) = (f4v){v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f4v*>(op + 4) = (f4v){v[4], v[5], v[6], v[7]};
+                } else {
+                    for (int e = 0; e < nvalid; ++e) op[e] = v[e];
+                }
+            } else {
+                unsigned short* op = reinterpret_cast<unsigned short*>(P.out) + oo + k0;
+                if (nvalid == 8) {
+                    s8v o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(v[e]);
+                    *reinterpret_cast<s8v*>(op) = o;
+                } else {
+                    for (int e = 0; e < nvalid; ++e) op[e] = f32_to_bf16_rn(v[e]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
+    MI355_REQUIRE(launch, "conv_gather: null launch");
+    const Mi355ConvLaunch& in = *launch;
+    MI355_REQUIRE(in.nprob >= 1 && in.nprob <= MI355_CONV_MAX_PROBLEMS, "conv_gather: nprob %d", in.nprob);
+    MI355_REQUIRE(in.K > 0 && in.weight && in.T > 0, "conv_gather: bad K/weight/T");
+    LaunchDev L;
+    memset(&L, 0, sizeof(L));
+    int tiles = 0;
+    bool flat = false;
+    const int C = in.prob[0].C;
+    for (int i = 0; i < in.nprob; ++i) {
+        const Mi355ConvProblem& s = in.prob[i];
+        MI355_REQUIRE(s.in && s.out, "conv_gather: problem %d null in/out", i);
+        MI355_REQUIRE(s.C == C && C > 0 && C % 8 == 0, "conv_gather: C must be a multiple of 8 and equal across problems");
+        MI355_REQUIRE(s.N > 0 && s.H > 0 && s.W > 0 && s.P > 0 && s.Q > 0, "conv_gather: problem %d bad dims", i);
+        MI355_REQUIRE(s.TR >= 0 && s.TS >= 0 && s.add_shift >= 0, "conv_gather: bad taps");
+        const long long in_bytes = (long long)s.N * s.H * s.W * s.C * 2;
+        MI355_REQUIRE(in_bytes < 0x7fffffffLL, "conv_gather: input tensor >= 2 GiB");
+        MI355_REQUIRE((long long)s.N * s.P * s.Q < 0x7fffffffLL, "conv_gather: M too large");
+        MI355_REQUIRE(((uintptr_t)s.in & 15) == 0 && ((uintptr_t)s.out & 15) == 0, "conv_gather: alignment");
+        ProbDev& d = L.p[i];
+        d.in = (const unsigned short*)s.in;  d.out = s.out;
+        d.addend = (const unsigned short*)s.addend;  d.mask = (const unsigned short*)s.mask;
+        d.N = s.N; d.H = s.H; d.W = s.W; d.C = s.C; d.P = s.P; d.Q = s.Q; d.sh = s.sh; d.sw = s.sw;
+        d.TR = s.TR; d.TS = s.TS; d.dh0 = s.dh0; d.dhs = s.dhs; d.dw0 = s.dw0; d.dws = s.dws;
+        d.r0 = s.r0; d.rs = s.rs; d.s0 = s.s0; d.ss = s.ss; d.S = s.S;
+        d.out_mh = s.out_mh; d.out_oh = s.out_oh; d.out_mw = s.out_mw; d.out_ow = s.out_ow;
+        d.out_sN = s.out_sN; d.out_sH = s.out_sH; d.out_sW = s.out_sW;
+        d.add_sN = s.add_sN; d.add_sH = s.add_sH; d.add_sW = s.add_sW; d.add_shift = s.add_shift;
+        d.M = s.N * s.P * s.Q;
+        d.in_bytes = (int)in_bytes;
+        d.tile_begin = tiles;
+        tiles += (int)cdiv(d.M, BM);
+    }
+    if (C % BK != 0) flat = true;
+    const long long w_bytes = (long long)in.K * in.T * C * 2;
+    MI355_REQUIRE(w_bytes < 0x7fffffffLL, "conv_gather: weight tensor >= 2 GiB");
+    MI355_REQUIRE(((uintptr_t)in.weight & 15) == 0, "conv_gather: weight alignment");
+    L.w = (const unsigned short*)in.weight;
+    L.bias = in.bias;
+    L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.act = in.act; L.out_f32 = in.out_f32;
+    L.n_tiles = (int)cdiv(in.K, BN);
+    L.w_bytes = (int)w_bytes;
+    const long long grid = (long long)tiles * L.n_tiles;
+    MI355_REQUIRE(grid > 0 && grid < 0x7fffffffLL, "conv_gather: grid");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    if (flat)
+        hipLaunchKernelGGL(conv_gather_kernel<true>, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES,
+                           (hipStream_t)stream, L);
+    else
+        hipLaunchKernelGGL(conv_gather_kernel<false>, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES,
+                           (hipStream_t)stream, L);
+    return check_launch("conv_gather_kernel");
+}

@@ -1,0 +1,241 @@
+// Weight gradient of the gather conv on gfx950 MFMA, grouped over problems sharing a weight:
+//
+//   dw[k][tap][c] += sum_m dy[m][k] * in[m @ tap][c]
+//
+// GEMM view: rows = K output channels, cols = C input channels of ONE tap, reduction = output
+// pixels m.  Both operands are stored pixel-major ([m][channel]), i.e. the reduction index is
+// the SLOW one, so the MFMA fragments (8 consecutive reduction elements per lane) are fetched
+// with ds_read_b64_tr_b16 (hardware transposed LDS read; semantics probed in
+// tools/probe_gfx950.hip [2]).  Tiles: 128 (k) x 128 (c) per block, 64 pixels per stage,
+// LDS-DMA staging (double-buffered), XOR swizzle on the 32-B column groups so that the
+// transposed reads of a 32-lane half hit 32 distinct 8-B cells.  The pixel range is split over
+// blocks (split_rows per block) and partial tiles are reduced with fp32 atomics issued as
+// 256-B contiguous row segments from an LDS-staged epilogue.
+//
+// Replaces the autograd weight-gradient of nn.Conv2d for every conv of
+// architectures/retinanet.py:272-287 (backbone, FPN, heads).
+#include "conv_common.h"
+
+using namespace mi355;
+
+namespace {
+
+constexpr int TK = 128, TC = 128, RM = 64, NTHREADS = 256;
+constexpr int STAGE_BYTES = (TK + TC) * RM * 2;           // 32 KiB
+constexpr int EPI_LD = TC + 4;
+constexpr int LDS_BYTES = (2 * STAGE_BYTES > TK * EPI_LD * 4) ? 2 * STAGE_BYTES : TK * EPI_LD * 4;
+
+struct FastDiv {
+    unsigned mul, shr, d;
+};
+static FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    if (d == 1) { f.mul = 0; f.shr = 0; return f; }
+    unsigned l = 0;
+    while ((1u << l) < d) ++l;
+    const unsigned p = 31 + l;
+    f.mul = (unsigned)(((1ull << p) + d - 1) / d);
+    f.shr = p - 32;
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned x, const FastDiv f) {   // x < 2^31
+    return f.d == 1 ? x : (__umulhi(x, f.mul) >> f.shr);
+}
+
+struct WProb {
+    const unsigned short* in;
+    const unsigned short* dy;
+    int N, H, W, C, P, Q, sh, sw;
+    int TR, TS, dh0, dhs, dw0, dws;
+    int r0, rs, s0, ss, S;
+    int M, in_bytes, dy_bytes;
+    int chunk_begin;
+    FastDiv dPQ, dQ;
+};
+
+struct WLaunch {
+    WProb p[MI355_CONV_MAX_PROBLEMS];
+    float* dw;
+    int nprob, K, T, k_tiles, c_tiles, ntaps, split_rows;
+};
+
+__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    // block -> (chunk, tap, k_tile, c_tile); tiles of one chunk are adjacent so that the
+    // activation rows they share stay in L2.
+    int b = blockIdx.x;
+    const int c_tile = b % L.c_tiles;  b /= L.c_tiles;
+    const int k_tile = b % L.k_tiles;  b /= L.k_tiles;
+    const int tap = b % L.ntaps;       b /= L.ntaps;
+    const int chunk = b;
+
+    WProb P = L.p[0];
+#pragma unroll
+    for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
+        if (i < L.nprob && chunk >= L.p[i].chunk_begin) P = L.p[i];
+    const int m_begin = (chunk - P.chunk_begin) * L.split_rows;
+    const int m_end = min(P.M, m_begin + L.split_rows);
+    const int ti = tap / P.TS, tj = tap - ti * P.TS;
+    const int dh = P.dh0 + ti * P.dhs, dw = P.dw0 + tj * P.dws;
+    const int wtap = (P.r0 + ti * P.rs) * P.S + (P.s0 + tj * P.ss);
+    const int k0 = k_tile * TK, c0 = c_tile * TC;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(P.in, (unsigned)P.in_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(P.dy, (unsigned)P.dy_bytes);
+
+    // staging: thread owns LDS (row = tid/16 + 16 i, slot = tid%16) and loads logical chunk
+    // slot ^ (f(row) << 1), f(row) = (row & 3) | ((row >> 3) & 1) << 2.
+    const int srow = tid >> 4, slot = tid & 15;
+    const int fsw = ((srow & 3) | (((srow >> 3) & 1) << 2)) << 1;
+    const int lchunk = slot ^ fsw;
+    const int ky = k0 + lchunk * 8;                    // dy channel of this thread's chunk
+    const int cx = c0 + lchunk * 8;                    // input channel of this thread's chunk
+    const bool ky_ok = ky + 8 <= L.K, cx_ok = cx + 8 <= P.C;
+
+    auto issue = [&](int step, int buf) {
+        unsigned char* sy = smem + buf * STAGE_BYTES;
+        unsigned char* sx = sy + TK * RM * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_begin + step * RM + srow + 16 * i;
+            const bool mok = m < m_end;
+            const unsigned offy = (mok && ky_ok) ? (unsigned)(m * L.K + ky) * 2u : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (LDS_PTR(void))(sy + (i * 256 + wv * 64) * 16),
+                                                     16, offy, 0, 0, 0);
+            unsigned offx = OOB_OFFSET;
+            if (mok && cx_ok) {
+                const unsigned n = fdiv((unsigned)m, P.dPQ);
+                const unsigned rem = (unsigned)m - n * (unsigned)(P.P * P.Q);
+                const unsigned p = fdiv(rem, P.dQ);
+                const unsigned q = rem - p * (unsigned)P.Q;
+                const int ih = (int)p * P.sh + dh, iw = (int)q * P.sw + dw;
+                if ((unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W)
+                    offx = (unsigned)((((int)n * P.H + ih) * P.W + iw) * P.C + cx) * 2u;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_PTR(void))(sx + (i * 256 + wv * 64) * 16),
+                                                     16, offx, 0, 0, 0);
+        }
+    };
+
+    f4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read addressing (16-lane group g, lane 4q+p): row 8g + q (+4), columns 4p..4p+3
+    const int wk = wv >> 1, wc = wv & 1;
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int f = (q4 | ((g & 1) << 2)) << 1;
+    const int row_lo = 8 * g + q4;
+    // logical 16-B chunk of (tile t of this wave, p4): 8*wk + 2t + (p4 >> 1) for dy, 8*wc + ... for x
+    const int half8 = (p4 & 1) * 8;
+
+    const int nsteps = (m_end - m_begin + RM - 1) / RM;
+    if (nsteps > 0) issue(0, 0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        const unsigned char* sy = smem + buf * STAGE_BYTES;
+        const unsigned char* sx = sy + TK * RM * 2;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            s8v af[4], bf[4];
+            const int r0 = sub * 32 + row_lo;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int cy = ((8 * wk + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
+                const int cxx = ((8 * wc + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
+                const s4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4v))(sy + r0 * 256 + cy));
+                const s4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4v))(sy + (r0 + 4) * 256 + cy));
+                const s4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4v))(sx + r0 * 256 + cxx));
+                const s4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4v))(sx + (r0 + 4) * 256 + cxx));
+                af[t] = (s8v){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                bf[t] = (s8v){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: LDS-staged, one 256-B contiguous atomic row segment per wave instruction
+    float* epi = reinterpret_cast<float*>(smem);
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                epi[(wk * 64 + i * 16 + fq * 4 + r) * EPI_LD + wc * 64 + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    const long long wrow = (long long)L.T * P.C;
+    for (int rr = wv; rr < TK; rr += 4) {
+        const int k = k0 + rr;
+        if (k >= L.K) break;
+        float* dst = L.dw + k * wrow + (long long)wtap * P.C + c0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = h * 64 + lane;
+            if (c0 + c < P.C) atomicAdd(dst + c, epi[rr * EPI_LD + c]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mi355_conv_wgrad(const Mi355ConvLaunch* launch, float* dw, int split_rows, void* stream) {
+    MI355_REQUIRE(launch && dw, "conv_wgrad: null argument");
+    const Mi355ConvLaunch& in = *launch;
+    MI355_REQUIRE(in.nprob >= 1 && in.nprob <= MI355_CONV_MAX_PROBLEMS, "conv_wgrad: nprob");
+    MI355_REQUIRE(in.K > 0 && in.K % 8 == 0 && in.T > 0, "conv_wgrad: K must be a positive multiple of 8");
+    MI355_REQUIRE(split_rows > 0 && split_rows % RM == 0, "conv_wgrad: split_rows must be a multiple of 64");
+    WLaunch L;
+    memset(&L, 0, sizeof(L));
+    const int C = in.prob[0].C;
+    const int ntaps = in.prob[0].TR * in.prob[0].TS;
+    int chunks = 0;
+    for (int i = 0; i < in.nprob; ++i) {
+        const Mi355ConvProblem& s = in.prob[i];
+        MI355_REQUIRE(s.in && s.out, "conv_wgrad: problem %d null in/dy", i);
+        MI355_REQUIRE(s.C == C && C % 8 == 0 && s.TR * s.TS == ntaps, "conv_wgrad: C%%8, taps equal across problems");
+        const long long in_bytes = (long long)s.N * s.H * s.W * s.C * 2;
+        const long long M = (long long)s.N * s.P * s.Q;
+        const long long dy_bytes = M * in.K * 2;
+        MI355_REQUIRE(in_bytes < 0x7fffffffLL && dy_bytes < 0x7fffffffLL && M > 0, "conv_wgrad: tensor >= 2 GiB");
+        MI355_REQUIRE(((uintptr_t)s.in & 15) == 0 && ((uintptr_t)s.out & 15) == 0, "conv_wgrad: alignment");
+        WProb& d = L.p[i];
+        d.in = (const unsigned short*)s.in;  d.dy = (const unsigned short*)s.out;
+        d.N = s.N; d.H = s.H; d.W = s.W; d.C = s.C; d.P = s.P; d.Q = s.Q; d.sh = s.sh; d.sw = s.sw;
+        d.TR = s.TR; d.TS = s.TS; d.dh0 = s.dh0; d.dhs = s.dhs; d.dw0 = s.dw0; d.dws = s.dws;
+        d.r0 = s.r0; d.rs = s.rs; d.s0 = s.s0; d.ss = s.ss; d.S = s.S;
+        d.M = (int)M; d.in_bytes = (int)in_bytes; d.dy_bytes = (int)dy_bytes;
+        d.dPQ = make_fastdiv((unsigned)(s.P * s.Q));
+        d.dQ = make_fastdiv((unsigned)s.Q);
+        d.chunk_begin = chunks;
+        chunks += (int)cdiv(M, split_rows);
+    }
+    if (ntaps == 0) return MI355_OK;
+    L.dw = dw;
+    L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.ntaps = ntaps; L.split_rows = split_rows;
+    L.k_tiles = (int)cdiv(in.K, TK);
+    L.c_tiles = (int)cdiv(C, TC);
+    const long long grid = (long long)chunks * ntaps * L.k_tiles * L.c_tiles;
+    MI355_REQUIRE(grid > 0 && grid < 0x7fffffffLL, "conv_wgrad: grid");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES,
+                       (hipStream_t)stream, L);
+    return check_launch("conv_wgrad_kernel");
+}

@@ -1,0 +1,227 @@
+"""Tensor-level wrappers over the conv entry points of the C ABI (include/mi355det_conv.h).
+
+Activations are NHWC bf16 tensors `[N,H,W,C]` (C a multiple of 8); weights are bf16 shadow copies
+`w_fwd [K][R*S][C]` / `w_dgr [C][R*S][Kpad]` produced by `prep_weight` from the fp32 masters.
+"""
+import ctypes
+
+import torch
+
+from ._lib import c_f32, c_i64, c_int, c_vp, call, ptr, require_gpu, stream_of
+
+MAX_PROBLEMS = 5
+
+
+class ConvProblem(ctypes.Structure):
+    _fields_ = [('in_', c_vp), ('out', c_vp), ('addend', c_vp), ('mask', c_vp),
+                ('N', c_int), ('H', c_int), ('W', c_int), ('C', c_int),
+                ('P', c_int), ('Q', c_int), ('sh', c_int), ('sw', c_int),
+                ('TR', c_int), ('TS', c_int), ('dh0', c_int), ('dhs', c_int),
+                ('dw0', c_int), ('dws', c_int),
+                ('r0', c_int), ('rs', c_int), ('s0', c_int), ('ss', c_int), ('S', c_int),
+                ('out_mh', c_int), ('out_oh', c_int), ('out_mw', c_int), ('out_ow', c_int),
+                ('out_sN', c_i64), ('out_sH', c_i64), ('out_sW', c_i64),
+                ('add_sN', c_i64), ('add_sH', c_i64), ('add_sW', c_i64),
+                ('add_shift', c_int), ('reserved', c_int)]
+
+
+class ConvLaunch(ctypes.Structure):
+    _fields_ = [('prob', ConvProblem * MAX_PROBLEMS), ('nprob', c_int), ('K', c_int),
+                ('weight', c_vp), ('T', c_int), ('act', c_int), ('bias', c_vp),
+                ('out_f32', c_int), ('reserved', c_int)]
+
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def _dp(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def out_hw(h, w, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+
+
+def fwd_problem(x, out_ptr, R, S, stride, pad, out_strides=None, K=None, addend=None, add_shift=0,
+                mask=None):
+    """Forward-conv problem over NHWC `x`; output NHWC [N,P,Q,K] unless `out_strides`
+    (sN, sH, sW in elements) says otherwise."""
+    N, H, W, C = x.shape
+    P, Q = out_hw(H, W, R, stride, pad)[0], out_hw(H, W, S, stride, pad)[1]
+    pr = ConvProblem()
+    pr.in_, pr.out, pr.addend, pr.mask = x.data_ptr(), out_ptr, _dp(addend), _dp(mask)
+    pr.N, pr.H, pr.W, pr.C, pr.P, pr.Q, pr.sh, pr.sw = N, H, W, C, P, Q, stride, stride
+    pr.TR, pr.TS, pr.dh0, pr.dhs, pr.dw0, pr.dws = R, S, -pad, 1, -pad, 1
+    pr.r0, pr.rs, pr.s0, pr.ss, pr.S = 0, 1, 0, 1, S
+    pr.out_mh, pr.out_oh, pr.out_mw, pr.out_ow = 1, 0, 1, 0
+    if out_strides is None:
+        out_strides = (P * Q * K, Q * K, K)
+    pr.out_sN, pr.out_sH, pr.out_sW = out_strides
+    if addend is not None:
+        pr.add_sN, pr.add_sH, pr.add_sW = addend.stride(0), addend.stride(1), addend.stride(2)
+    pr.add_shift = add_shift
+    return pr
+
+
+def dgrad_problems(dy, dx_ptr, H, W, Cin, R, S, stride, pad, addend=None, mask=None):
+    """Data-gradient problems: one per output-parity class (stride^2 classes; 1 for stride 1).
+    dy: NHWC [N,P,Q,Kpad]; dx: NHWC [N,H,W,Cin]."""
+    N, P, Q, Kp = dy.shape
+    probs = []
+    for ph in range(stride):
+        for pw in range(stride):
+            rf, sf = (ph + pad) % stride, (pw + pad) % stride
+            TR = len(range(rf, R, stride))
+            TS = len(range(sf, S, stride))
+            Pp, Qp = (H - ph + stride - 1) // stride, (W - pw + stride - 1) // stride
+            if Pp <= 0 or Qp <= 0:
+                continue
+            pr = ConvProblem()
+            pr.in_, pr.out, pr.addend, pr.mask = dy.data_ptr(), dx_ptr, _dp(addend), _dp(mask)
+            pr.N, pr.H, pr.W, pr.C, pr.P, pr.Q, pr.sh, pr.sw = N, P, Q, Kp, Pp, Qp, 1, 1
+            pr.TR, pr.TS = TR, TS
+            pr.dh0, pr.dhs = (ph + pad - rf) // stride, -1
+            pr.dw0, pr.dws = (pw + pad - sf) // stride, -1
+            pr.r0, pr.rs, pr.s0, pr.ss, pr.S = rf, stride, sf, stride, S
+            pr.out_mh, pr.out_oh, pr.out_mw, pr.out_ow = stride, ph, stride, pw
+            pr.out_sN, pr.out_sH, pr.out_sW = H * W * Cin, W * Cin, Cin
+            if addend is not None:      # addend indexed on the dx grid (h, w) = (p*stride+ph, ...)
+                pr.add_sN = addend.stride(0)
+                pr.add_sH, pr.add_sW = addend.stride(1) * stride, addend.stride(2) * stride
+                pr.addend = addend.data_ptr() + 2 * (ph * addend.stride(1) + pw * addend.stride(2))
+            probs.append(pr)
+    return probs
+
+
+def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE, out_f32=False):
+    for i in range(0, len(problems), MAX_PROBLEMS):
+        chunk = problems[i:i + MAX_PROBLEMS]
+        L = ConvLaunch()
+        for j, pr in enumerate(chunk):
+            L.prob[j] = pr
+        L.nprob, L.K, L.weight, L.T = len(chunk), K, weight.data_ptr(), T
+        L.act, L.bias, L.out_f32 = act, _dp(bias), 1 if out_f32 else 0
+        call('mi355_conv_gather', ctypes.byref(L), stream_of(stream_tensor))
+
+
+def launch_wgrad(problems, K, T, dw, split_rows, stream_tensor):
+    L = ConvLaunch()
+    for j, pr in enumerate(problems):
+        L.prob[j] = pr
+    L.nprob, L.K, L.T = len(problems), K, T
+    call('mi355_conv_wgrad', ctypes.byref(L), ptr(dw), c_int(split_rows), stream_of(stream_tensor))
+
+
+def pick_split_rows(total_rows, tiles_per_chunk, target_blocks=1024):
+    """Rows of the pixel reduction per block so that the launch has ~target_blocks blocks."""
+    chunks = max(1, target_blocks // max(1, tiles_per_chunk))
+    rows = -(-total_rows // chunks)
+    rows = max(256, -(-rows // 64) * 64)
+    return rows
+
+
+# ---------------------------------------------------------------- simple single-problem helpers
+def conv_fwd(x, w_fwd, K, R, S, stride, pad, bias=None, act=ACT_NONE, addend=None, add_shift=0,
+             out_f32=False):
+    require_gpu(x, w_fwd)
+    N, H, W, C = x.shape
+    P, Q = out_hw(H, W, R, stride, pad)[0], out_hw(H, W, S, stride, pad)[1]
+    out = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    pr = fwd_problem(x, out.data_ptr(), R, S, stride, pad, K=K, addend=addend, add_shift=add_shift)
+    launch_gather([pr], w_fwd, K, R * S, x, bias=bias, act=act, out_f32=out_f32)
+    return out
+
+
+def conv_dgrad(dy, w_dgr, H, W, Cin, R, S, stride, pad, addend=None, mask=None):
+    require_gpu(dy, w_dgr)
+    N = dy.shape[0]
+    dx = torch.empty((N, H, W, Cin), dtype=torch.bfloat16, device=dy.device)
+    probs = dgrad_problems(dy, dx.data_ptr(), H, W, Cin, R, S, stride, pad, addend=addend, mask=mask)
+    launch_gather(probs, w_dgr, Cin, R * S, dy)
+    return dx
+
+
+def conv_wgrad(x, dy, R, S, stride, pad, split_rows=None, out=None):
+    """-> G fp32 [Kpad][R*S][C] = sum_m dy[m][k] * x[m @ tap][c] (accumulates into `out`)."""
+    require_gpu(x, dy)
+    N, H, W, C = x.shape
+    Kp = dy.shape[3]
+    T = R * S
+    if out is None:
+        out = torch.zeros((Kp, T, C), dtype=torch.float32, device=x.device)
+    pr = fwd_problem(x, dy.data_ptr(), R, S, stride, pad, K=Kp)
+    M = N * pr.P * pr.Q
+    if split_rows is None:
+        split_rows = pick_split_rows(M, T * (-(-Kp // 128)) * (-(-C // 128)))
+    launch_wgrad([pr], Kp, T, out, split_rows, x)
+    return out
+
+
+# ---------------------------------------------------------------- aux kernels
+def nchw_to_nhwc(img, cpad):
+    require_gpu(img)
+    img = img.contiguous().float()
+    N, C, H, W = img.shape
+    out = torch.empty((N, H, W, cpad), dtype=torch.bfloat16, device=img.device)
+    call('mi355_nchw_to_nhwc_bf16', ptr(img), ptr(out), c_int(N), c_int(C), c_int(H), c_int(W),
+         c_int(cpad), stream_of(img))
+    return out
+
+
+def prep_weight(w, cpad, scale, w_fwd, w_dgr):
+    """w: fp32 [K,C,R,S] (any strides) -> bf16 shadows (either may be None)."""
+    K, C, R, S = w.shape
+    sk, sc, sr, ss = w.stride()
+    call('mi355_prep_weight', ptr(w), c_i64(sk), c_i64(sc), c_i64(sr), c_i64(ss), c_int(K), c_int(C),
+         c_int(R), c_int(S), c_int(cpad), ptr(scale), ptr(w_fwd), ptr(w_dgr), stream_of(w))
+
+
+def bn_fold(bn, scale, shift):
+    call('mi355_bn_fold', ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+         c_f32(bn.eps), c_int(bn.num_features), ptr(scale), ptr(shift), stream_of(scale))
+
+
+def colsum(g, out):
+    M = g.numel() // g.shape[-1]
+    call('mi355_colsum_bf16', ptr(g), c_i64(M), c_int(g.shape[-1]), ptr(out), stream_of(g))
+
+
+def conv_param_grads(G, w, cpad, scale, colsum_, bn, dW, dgamma, dbeta, accumulate=False):
+    K, C, R, S = w.shape
+    sk, sc, sr, ss = w.stride()
+    assert dW.stride() == w.stride()
+    call('mi355_conv_param_grads', ptr(G), ptr(w), c_i64(sk), c_i64(sc), c_i64(sr), c_i64(ss),
+         c_int(K), c_int(C), c_int(R), c_int(S), c_int(cpad), ptr(scale), ptr(colsum_),
+         ptr(bn.running_mean if bn is not None else None),
+         ptr(bn.running_var if bn is not None else None), c_f32(bn.eps if bn is not None else 0.0),
+         ptr(dW), ptr(dgamma), ptr(dbeta), c_int(1 if accumulate else 0), stream_of(G))
+
+
+def maxpool_fwd(x):
+    N, H, W, C = x.shape
+    P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, P, Q, C), dtype=torch.bfloat16, device=x.device)
+    idx = torch.empty((N, P, Q, C), dtype=torch.int8, device=x.device)
+    call('mi355_maxpool3x3s2_fwd', ptr(x), ptr(out), ptr(idx), c_int(N), c_int(H), c_int(W), c_int(C),
+         stream_of(x))
+    return out, idx
+
+
+def maxpool_bwd(gout, idx, in_shape, relu_mask=None):
+    N, H, W, C = in_shape
+    gin = torch.empty(in_shape, dtype=torch.bfloat16, device=gout.device)
+    call('mi355_maxpool3x3s2_bwd', ptr(gout), ptr(idx), ptr(gin), ptr(relu_mask), c_int(N), c_int(H),
+         c_int(W), c_int(C), stream_of(gout))
+    return gin
+
+
+def sumpool2x2(src, dst, accumulate):
+    N, H, W, C = src.shape
+    call('mi355_sumpool2x2_bf16', ptr(src), ptr(dst), c_int(N), c_int(H), c_int(W), c_int(C),
+         c_int(1 if accumulate else 0), stream_of(src))
+
+
+def relu_mask(x, ref, out=None):
+    out = torch.empty_like(x) if out is None else out
+    call('mi355_relu_mask_bf16', ptr(x), ptr(ref), ptr(out), c_i64(x.numel()), stream_of(x))
+    return out

@@ -1,0 +1,253 @@
+"""GPU parity of the MFMA conv engine (through the C ABI) against torch fp32 CPU convs of the
+same bf16-rounded operands.  fp32 accumulation of exact bf16 products: an fp32-output conv must
+agree to ~1e-3 relative (summation order only); bf16 outputs add one rounding (2^-9 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda', 0)
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return _bf(torch.randn(shape, generator=g) * scale)
+
+
+def _close(got, ref, tol):
+    got, ref = got.float().cpu(), ref.float()
+    err = (got - ref).abs().max().item()
+    mag = ref.abs().max().item() + 1e-12
+    assert err <= tol * mag, 'max err %.4g vs magnitude %.4g (tol %.3g)' % (err, mag, tol)
+
+
+def _shadow(w, dev, cpad=None, scale=None):
+    """fp32 OIHW master (channels_last on device) -> bf16 shadows via the HIP prep kernel."""
+    from objectdetection.pytorch_amd import ops_conv
+    K, C, R, S = w.shape
+    cpad = C if cpad is None else cpad
+    kpad = (K + 7) // 8 * 8
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last)
+    w_fwd = torch.zeros((K, R * S, cpad), dtype=torch.bfloat16, device=dev)
+    w_dgr = torch.zeros((C, R * S, kpad), dtype=torch.bfloat16, device=dev)
+    ops_conv.prep_weight(wd, cpad, scale, w_fwd, w_dgr)
+    return wd, w_fwd, w_dgr
+
+
+CASES = [  # N, H, W, C, K, R, stride, pad
+    (2, 20, 24, 64, 128, 3, 1, 1),
+    (2, 17, 23, 128, 256, 1, 1, 0),
+    (2, 18, 22, 128, 256, 1, 2, 0),
+    (2, 19, 21, 64, 64, 3, 2, 1),
+    (1, 33, 31, 8, 64, 7, 2, 3),        # stem shape class (flat reduction, C = 8)
+    (2, 9, 11, 40, 24, 1, 1, 0),        # C, K not multiples of 64/128 (EfficientNet-like)
+    (1, 8, 8, 256, 720, 3, 1, 1),       # cls output conv
+    (3, 5, 7, 256, 36, 3, 1, 1),        # reg output conv (K % 8 != 0)
+    (1, 4, 4, 2048, 256, 3, 2, 1),      # P6
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_fwd(dev, case):
+    from objectdetection.pytorch_amd import ops_conv
+    N, H, W, C, K, R, stride, pad = case
+    x = _mk((N, C, H, W), 1)
+    w = _mk((K, C, R, R), 2, scale=(2.0 / (C * R * R)) ** 0.5)
+    b = _mk((K,), 3).float()
+    ref = F.conv2d(x, w, b, stride, pad)
+    _, w_fwd, _ = _shadow(w, dev)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    out = ops_conv.conv_fwd(xh, w_fwd, K, R, R, stride, pad, bias=b.to(dev), out_f32=True)
+    _close(out.permute(0, 3, 1, 2), ref, 2e-3)
+    out = ops_conv.conv_fwd(xh, w_fwd, K, R, R, stride, pad, bias=b.to(dev), act=ops_conv.ACT_RELU)
+    _close(out.permute(0, 3, 1, 2), F.relu(ref), 1e-2)
+    out = ops_conv.conv_fwd(xh, w_fwd, K, R, R, stride, pad, bias=b.to(dev), act=ops_conv.ACT_SIGMOID,
+                            out_f32=True)
+    _close(out.permute(0, 3, 1, 2), torch.sigmoid(ref), 2e-3)
+
+
+def test_conv_fwd_bn_fold_addend_relu(dev):
+    """conv -> frozen BN -> (+ residual) -> ReLU, utils_resnet.py:60-80."""
+    from objectdetection.pytorch_amd import ops_conv
+    N, H, W, C, K = 2, 14, 14, 64, 256
+    x, w = _mk((N, C, H, W), 1), _mk((K, C, 1, 1), 2, 0.2)
+    res = _mk((N, K, H, W), 3)
+    bn = torch.nn.BatchNorm2d(K).eval()
+    g = torch.Generator().manual_seed(4)
+    bn.weight.data.uniform_(0.5, 1.5, generator=g)
+    bn.bias.data.normal_(0, 0.1, generator=g)
+    bn.running_mean.normal_(0, 0.1, generator=g)
+    bn.running_var.uniform_(0.5, 1.5, generator=g)
+    ref = F.relu(bn(F.conv2d(x, w)) + res)
+    bnd = torch.nn.BatchNorm2d(K).to(dev).eval()
+    bnd.load_state_dict(bn.state_dict())
+    scale = torch.empty(K, device=dev)
+    shift = torch.empty(K, device=dev)
+    ops_conv.bn_fold(bnd, scale, shift)
+    _, w_fwd, _ = _shadow(w, dev, scale=scale)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    rh = res.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    out = ops_conv.conv_fwd(xh, w_fwd, K, 1, 1, 1, 0, bias=shift, act=ops_conv.ACT_RELU, addend=rh)
+    _close(out.permute(0, 3, 1, 2), ref, 1.5e-2)
+
+
+def test_conv_fwd_upsample_addend(dev):
+    """lateral 1x1 + nearest-2x upsampled coarser map, retinanet.py:55-56."""
+    from objectdetection.pytorch_amd import ops_conv
+    N, H, W, C, K = 2, 10, 14, 128, 256
+    x, w = _mk((N, C, H, W), 1), _mk((K, C, 1, 1), 2, 0.1)
+    coarse = _mk((N, K, H // 2, W // 2), 3)
+    ref = F.conv2d(x, w) + F.interpolate(coarse, scale_factor=2, mode='nearest')
+    _, w_fwd, _ = _shadow(w, dev)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    ch = coarse.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    out = ops_conv.conv_fwd(xh, w_fwd, K, 1, 1, 1, 0, addend=ch, add_shift=1)
+    _close(out.permute(0, 3, 1, 2), ref, 1e-2)
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[3] != 8])
+def test_conv_dgrad(dev, case):
+    from objectdetection.pytorch_amd import ops_conv
+    N, H, W, C, K, R, stride, pad = case
+    w = _mk((K, C, R, R), 2, scale=(2.0 / (K * R * R)) ** 0.5)
+    P, Q = ops_conv.out_hw(H, W, R, stride, pad)
+    dy = _mk((N, K, P, Q), 5)
+    ref = torch.nn.grad.conv2d_input((N, C, H, W), w, dy, stride, pad)
+    _, _, w_dgr = _shadow(w, dev)
+    kpad = w_dgr.shape[2]
+    dyh = torch.zeros((N, P, Q, kpad), dtype=torch.bfloat16, device=dev)
+    dyh[..., :K] = dy.permute(0, 2, 3, 1).to(dev).to(torch.bfloat16)
+    dx = ops_conv.conv_dgrad(dyh, w_dgr, H, W, C, R, R, stride, pad)
+    _close(dx.permute(0, 3, 1, 2), ref, 1e-2)
+    # fused residual-grad accumulate + ReLU mask (Bottleneck backward, utils_resnet.py:77-78)
+    add = _mk((N, C, H, W), 6)
+    msk = _mk((N, C, H, W), 7)
+    ref2 = (ref + add) * (msk > 0).float()
+    dx = ops_conv.conv_dgrad(dyh, w_dgr, H, W, C, R, R, stride, pad,
+                             addend=add.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16),
+                             mask=msk.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16))
+    _close(dx.permute(0, 3, 1, 2), ref2, 1e-2)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_wgrad(dev, case):
+    from objectdetection.pytorch_amd import ops_conv
+    N, H, W, C, K, R, stride, pad = case
+    x = _mk((N, C, H, W), 1)
+    P, Q = ops_conv.out_hw(H, W, R, stride, pad)
+    dy = _mk((N, K, P, Q), 5)
+    ref = torch.nn.grad.conv2d_weight(x, (K, C, R, R), dy, stride, pad)      # [K,C,R,S]
+    kpad = (K + 7) // 8 * 8
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    dyh = torch.zeros((N, P, Q, kpad), dtype=torch.bfloat16, device=dev)
+    dyh[..., :K] = dy.permute(0, 2, 3, 1).to(dev).to(torch.bfloat16)
+    for split in (None, 64):
+        G = ops_conv.conv_wgrad(xh, dyh, R, R, stride, pad, split_rows=split)   # [Kpad][T][C]
+        got = G[:K].reshape(K, R, R, C).permute(0, 3, 1, 2)
+        _close(got, ref, 2e-3)
+        if kpad > K:
+            assert float(G[K:].abs().max()) == 0.0
+
+
+def test_grouped_heads_shared_weights(dev):
+    """Five pyramid levels, one launch, outputs concatenated along A (retinanet.py:285-287)."""
+    from objectdetection.pytorch_amd import ops_conv
+    N, C, K = 2, 256, 720
+    sizes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    w = _mk((K, C, 3, 3), 2, scale=(2.0 / (C * 9)) ** 0.5)
+    b = _mk((K,), 3).float()
+    _, w_fwd, _ = _shadow(w, dev)
+    xs = [_mk((N, C, h, ww), 10 + i) for i, (h, ww) in enumerate(sizes)]
+    A = sum(h * ww for h, ww in sizes) * 9
+    out = torch.empty((N, A, 80), dtype=torch.float32, device=dev)
+    probs, off, keep = [], 0, []
+    for x, (h, ww) in zip(xs, sizes):
+        xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+        keep.append(xh)
+        probs.append(ops_conv.fwd_problem(xh, out.data_ptr() + 4 * off * 80, 3, 3, 1, 1,
+                                          out_strides=(A * 80, ww * K, K), K=K))
+        off += h * ww * 9
+    ops_conv.launch_gather(probs, w_fwd, K, 9, out, bias=b.to(dev), act=ops_conv.ACT_SIGMOID, out_f32=True)
+    ref = torch.cat([torch.sigmoid(F.conv2d(x, w, b, 1, 1)).permute(0, 2, 3, 1).reshape(N, -1, 80)
+                     for x in xs], dim=1)
+    _close(out, ref, 2e-3)
+    # grouped wgrad over the same five problems
+    dys = [_mk((N, K, h, ww), 20 + i) for i, (h, ww) in enumerate(sizes)]
+    G = torch.zeros((K, 9, C), dtype=torch.float32, device=dev)
+    wprobs, keep2 = [], []
+    for xh, dy, (h, ww) in zip(keep, dys, sizes):
+        dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+        keep2.append(dyh)
+        wprobs.append(ops_conv.fwd_problem(xh, dyh.data_ptr(), 3, 3, 1, 1, K=K))
+    ops_conv.launch_wgrad(wprobs, K, 9, G, 128, out)
+    refw = sum(torch.nn.grad.conv2d_weight(x, (K, C, 3, 3), dy, 1, 1) for x, dy in zip(xs, dys))
+    _close(G.reshape(K, 3, 3, C).permute(0, 3, 1, 2), refw, 2e-3)
+
+
+def test_param_grads_with_frozen_bn(dev):
+    """dW, dgamma, dbeta of conv -> BN(eval) from the raw wgrad + column sums."""
+    from objectdetection.pytorch_amd import ops_conv
+    N, H, W, C, K = 2, 9, 9, 64, 64
+    x = _mk((N, C, H, W), 1)
+    w = _mk((K, C, 3, 3), 2, 0.05).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(K).eval()
+    g = torch.Generator().manual_seed(4)
+    bn.weight.data.uniform_(0.5, 1.5, generator=g)
+    bn.bias.data.normal_(0, 0.1, generator=g)
+    bn.running_mean.normal_(0, 0.1, generator=g)
+    bn.running_var.uniform_(0.5, 1.5, generator=g)
+    dy = _mk((N, K, H, W), 5)
+    bn(F.conv2d(x, w, None, 1, 1)).backward(dy)
+    bnd = torch.nn.BatchNorm2d(K).to(dev).eval()
+    bnd.load_state_dict(bn.state_dict())
+    scale, shift = torch.empty(K, device=dev), torch.empty(K, device=dev)
+    ops_conv.bn_fold(bnd, scale, shift)
+    wd = w.detach().to(dev).contiguous(memory_format=torch.channels_last)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    G = ops_conv.conv_wgrad(xh, dyh, 3, 3, 1, 1)
+    cs = torch.zeros(K, device=dev)
+    ops_conv.colsum(dyh, cs)
+    _close(cs, dy.sum((0, 2, 3)), 1e-3)
+    dW = torch.empty_like(wd)
+    dgam, dbet = torch.empty(K, device=dev), torch.empty(K, device=dev)
+    ops_conv.conv_param_grads(G, wd, C, scale, cs, bnd, dW, dgam, dbet)
+    _close(dW, w.grad, 2e-3)
+    _close(dgam, bn.weight.grad, 5e-3)
+    _close(dbet, bn.bias.grad, 1e-3)
+
+
+def test_maxpool_and_friends(dev):
+    from objectdetection.pytorch_amd import ops_conv
+    N, C, H, W = 2, 64, 21, 26
+    x = F.relu(_mk((N, C, H, W), 1)).requires_grad_(True)      # many ties at 0 after ReLU
+    y = F.max_pool2d(x, 3, 2, 1)
+    gy = _mk(tuple(y.shape), 2)
+    y.backward(gy)
+    xh = x.detach().permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    out, idx = ops_conv.maxpool_fwd(xh)
+    assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), y.detach())
+    gin = ops_conv.maxpool_bwd(gy.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16), idx,
+                               tuple(xh.shape))
+    _close(gin.permute(0, 3, 1, 2), x.grad, 1e-2)
+    # nearest-upsample backward
+    src = _mk((N, C, 9, 7), 3)
+    ref = F.avg_pool2d(F.pad(src, (0, 1, 0, 1)), 2) * 4
+    dst = torch.zeros((N, 5, 4, C), dtype=torch.bfloat16, device=dev)
+    ops_conv.sumpool2x2(src.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16), dst, False)
+    _close(dst.permute(0, 3, 1, 2), ref, 1e-2)
+    # NCHW fp32 -> NHWC bf16 (channel pad)
+    img = torch.randn(2, 3, 10, 12)
+    o = ops_conv.nchw_to_nhwc(img.to(dev), 8)
+    assert torch.equal(o[..., :3].float().cpu(), _bf(img).permute(0, 2, 3, 1))
+    assert float(o[..., 3:].float().abs().max()) == 0.0
