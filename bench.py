@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec, RetinaNet-R50 training step, 512x512, batch 16 per GPU
+(BASELINE.json `metric`, configs[1]) on N MI355X of one node.
+
+One step = train.py:292-321 of the reference: zero_grad -> forward + FocalLoss -> backward ->
+(N > 1: RCCL all-reduce of the flat gradient arena) -> clip_grad_norm_(0.1) -> AdamW(lr 1e-4,
+wd 5e-4).  Inputs are synthetic (tests/synth.py: N(0,1) images, 8 boxes/img padded with -1 rows
+to 16) and already resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) extended with `roofline`
+(dominant kernels = the MFMA convs, algorithmic FLOPs / HIP-event time of exactly those launches)
+and `cpu_baseline` (the fp32 oracle port timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+import torch.distributed as dist   # noqa: E402
+
+import synth                # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparse figure)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--depth', type=int, default=50)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--graph', type=int, default=int(os.environ.get('MI355_GRAPH', '0')))
+    return ap.parse_args()
+
+
+def build_model(depth, num_classes, dev):
+    from objectdetection.pytorch_amd.architectures import retinanet
+    model = retinanet.retinanet(depth, num_classes=num_classes)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    # deterministic non-degenerate weights (random frozen-BN statistics, head outputs in a useful
+    # range: see tests/synth.py) - random-init weights of the named architecture
+    sd = synth.synth_state_dict(shapes, seed=0, gain=0.78 if depth >= 50 else 0.87)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    model.train()
+    model.freeze_bn()                       # train.py:273-277
+    return model, sd
+
+
+def clip_grad_norm_flat_(arena, max_norm):
+    """torch.nn.utils.clip_grad_norm_ semantics (train.py:320) on the flat gradient arena: one
+    norm kernel + one scale kernel, no host sync."""
+    total = torch.linalg.vector_norm(arena)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    arena.mul_(coef)
+    return total
+
+
+def conv_flops(plan):
+    """Algorithmic conv FLOPs of one training step (2 x MAC, true channel counts):
+    forward + weight-gradient for every conv, data-gradient for all but the stem."""
+    fwd = 0
+    dgrad = 0
+    B = plan.B
+
+    def out_pixels(spec, shapes):
+        return sum(n * p * q for (n, p, q) in shapes)
+
+    # walk the forward launches recorded by the plan
+    for L in plan.fwd_launches:
+        spec, probs = L
+        for (n, p, q) in probs:
+            f = 2.0 * n * p * q * spec.K * spec.C * spec.T
+            fwd += f
+            if spec.need_dgrad:
+                dgrad += f
+    return fwd, fwd + dgrad + fwd     # (forward, training = fwd + dgrad + wgrad)
+
+
+def time_conv_kernels(plan, iters):
+    """HIP-event time of ONLY the MFMA conv launches of one step (forward gather convs,
+    backward gather convs = dgrad, wgrad), replayed back-to-back on the launch stream."""
+    names = ('mi355_conv_gather', 'mi355_conv_wgrad')
+    steps = [s for s in plan.fwd_steps + plan.bwd_steps if s[2] in names]
+    st = torch.cuda.current_stream()
+    plan.grad_arenas[0].zero_()
+    plan._run(steps, st.cuda_stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        plan._run(steps, st.cuda_stream)
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters, len(steps)
+
+
+def cpu_baseline(depth, size, sd, num_classes):
+    """fp32 oracle (oracle/ref_cpu.py = CPU port of the reference path) forward + loss + backward
+    on a bounded sample of the same workload."""
+    from oracle import ref_cpu
+    nthreads = torch.get_num_threads()
+    B = 2
+    img = torch.from_numpy(synth.synth_images(B, size, size, seed=1))
+    ann = torch.from_numpy(synth.synth_annotations(B, size, size, 8, 16, num_classes, seed=2))
+    p = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype == np.float32 and 'running' not in k)
+         for k, v in sd.items()}
+
+    def step():
+        cl, rl = ref_cpu.retinanet_loss(p, img, ann, depth)
+        (cl.mean() + rl.mean()).backward()
+        for t in p.values():
+            t.grad = None
+
+    step()                                   # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 8):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {'value': round(B * n / dt, 3), 'unit': 'images/sec', 'cores': nthreads, 'kind': 'port',
+            'sample': '%d steps of batch %d, RetinaNet-R%d %dx%d fp32 fwd+loss+bwd (no optimizer), '
+                      'torch CPU oracle' % (n, B, depth, size, size)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU (no CPU fallback in the product path)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    num_classes = 80
+    model, sd = build_model(args.depth, num_classes, dev)
+    B, S = args.batch, args.size
+    # each rank owns its shard of the global batch (weak scaling: per-GPU batch fixed)
+    img = torch.from_numpy(synth.synth_images(B, S, S, seed=100 + rank)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(B, S, S, 8, 16, num_classes, seed=200 + rank)).to(dev)
+    params = [p for p in model.parameters()]
+    try:
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=5e-4, fused=True)   # train.py:259-260
+    except Exception:
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=5e-4)
+    loss_acc = torch.zeros(2, device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)                       # train.py:292
+        cl, rl = model(img, ann)                              # train.py:303
+        loss = cl.mean() + rl.mean()                          # train.py:312-314
+        loss.backward()                                       # train.py:319
+        plan = model._plans[next(iter(model._plans))]
+        arena = plan.grad_arenas[plan.last_arena]
+        if world > 1:
+            dist.all_reduce(arena, op=dist.ReduceOp.AVG)      # DP gradient exchange over xGMI
+        clip_grad_norm_flat_(arena, 0.1)                      # train.py:320
+        opt.step()                                            # train.py:321
+        loss_acc.add_(torch.cat([cl.detach(), rl.detach()]))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+    out = {
+        'metric': 'images/sec training (RetinaNet-R%d, %dx%d, bs=%d/GPU)' % (args.depth, S, S, B),
+        'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'RetinaNet-R%d FPN, %dx%d, bf16 MFMA convs (fp32 accumulate, fp32 loss '
+                               'and optimizer), batch=%d/GPU, fwd+FocalLoss+bwd+clip+AdamW, frozen BN'
+                               % (args.depth, S, S, B),
+                   'global_batch': world * B, 'parallelism': 'dp%d' % world,
+                   'final_loss': [round(float(v), 5) for v in (loss_acc / (args.warmup + args.steps)).tolist()]},
+    }
+    plan = model._plans[next(iter(model._plans))]
+    if rank == 0 and not args.no_roofline:
+        fwd_f, train_f = conv_flops(plan)
+        conv_ms, nlaunch = time_conv_kernels(plan, 5)
+        ach = train_f / (conv_ms * 1e-3) / 1e12
+        out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                           'kernel': 'conv_gather_kernel + conv_wgrad_kernel (%d launches/step)' % nlaunch,
+                           'algorithmic_gflop_per_image': round(train_f / B / 1e9, 2),
+                           'conv_ms_per_step': round(conv_ms, 3)}
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline(args.depth, S, sd, num_classes)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -59,12 +59,17 @@ int mi355_focal_loss_fwd(const float* cls, const float* reg, const float* anchor
  * (device memory).  grad_cls_mode: 0 -> d/dprob as fp32 [B][A][C];
  *                                  1 -> d/dlogit (= d/dprob * p * (1-p)) as bf16 [B][A][C]
  *                                       (feeds the classification-head dgrad/wgrad directly).
- * grad_reg: fp32 [B][A][4] (mode 0) or bf16 (mode 1). */
+ * grad_reg: fp32 [B][A][4] (mode 0) or bf16 (mode 1).  In mode 1, cell_anchors > 0 writes both
+ * gradients per pyramid cell (cell_anchors anchors each) with padded pitches, i.e. as the NHWC
+ * rows the head convs consume: element offset of grad_cls (b, a, c) =
+ * (b*(A/cell_anchors) + a/cell_anchors)*cls_cell_pitch + (a%cell_anchors)*C + c, of grad_reg
+ * (b, a, j) = (...)*reg_cell_pitch + (a%cell_anchors)*4 + j  (pad columns are never written:
+ * zero the buffers once). */
 int mi355_focal_loss_bwd(const float* cls, const float* reg, const float* anchors,
                          const float* annot, const int32_t* argmax, const int8_t* state,
                          const int32_t* num_pos, const float* grad_losses, int B, int A, int C,
                          int M, float alpha, int grad_mode, void* grad_cls, void* grad_reg,
-                         void* stream);
+                         int cell_anchors, int cls_cell_pitch, int reg_cell_pitch, void* stream);
 
 /* ---- decode + clip : architectures/utils.py:26-53 (BBoxTransform), :61-71 (ClipBoxes) ---- */
 /* boxes [1 or B][A][4] (boxes_batched = 0/1), deltas [B][A][4] -> out [B][A][4].

@@ -41,6 +41,7 @@ typedef struct Mi355ConvProblem {
     int64_t add_sN, add_sH, add_sW;
     int32_t add_shift;
     int32_t reserved;
+    int64_t in_sN;       /* batch stride of `in` in elements; 0 = dense (H*W*C) */
 } Mi355ConvProblem;
 
 typedef struct Mi355ConvLaunch {
@@ -52,7 +53,7 @@ typedef struct Mi355ConvLaunch {
     int32_t act;          /* 0 none, 1 relu, 2 sigmoid */
     const float* bias;    /* optional fp32 [K] (conv bias or folded frozen-BN shift) */
     int32_t out_f32;      /* 0: bf16 out, 1: fp32 out */
-    int32_t reserved;
+    int32_t flags;        /* bit 0: apply the mask BEFORE the addend: act(acc*mask + addend) */
 } Mi355ConvLaunch;
 
 /* out = act( gatherconv(in, weight) + bias + addend ) * (mask > 0) for every problem. */
@@ -61,7 +62,8 @@ int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream);
 /* Weight gradient of the same gather conv, grouped over problems that share the weight:
  *   dw[k][t][c] += sum_m dy[m][k] * in[m @ tap t][c]        (fp32 atomics; zero dw first)
  * Problem fields used: in, N,H,W,C, P,Q, sh,sw, TR,TS,dh0,dhs,dw0,dws, r0,rs,s0,ss,S;
- * `out` holds the dense bf16 dy [N*P*Q][K] of that problem. dw is fp32 [K][T][C]. */
+ * `out` holds the bf16 dy of that problem, [N][P*Q][K] with batch stride out_sN elements
+ * (0 = dense). dw is fp32 [K][T][C]. */
 int mi355_conv_wgrad(const Mi355ConvLaunch* launch, float* dw, int split_rows, void* stream);
 
 /* ---- elementwise / layout helpers of the conv path --------------------------------------- */

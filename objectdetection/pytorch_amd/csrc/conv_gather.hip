@@ -39,6 +39,7 @@ struct ProbDev {
     int out_mh, out_oh, out_mw, out_ow;
     long long out_sN, out_sH, out_sW;
     long long add_sN, add_sH, add_sW;
+    long long in_sN;
     int add_shift;
     int tile_begin;
     int M;
@@ -49,7 +50,7 @@ struct LaunchDev {
     ProbDev p[MI355_CONV_MAX_PROBLEMS];
     const unsigned short* w;
     const float* bias;
-    int nprob, K, T, act, out_f32, n_tiles, w_bytes;
+    int nprob, K, T, act, out_f32, n_tiles, w_bytes, flags;
 };
 
 __device__ __forceinline__ float activate(float v, int act) {
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
             const int n = m / PQ, rem = m - n * PQ, p = rem / P.Q, q = rem - p * P.Q;
             a_ih0[i] = p * P.sh + P.dh0;
             a_iw0[i] = q * P.sw + P.dw0;
-            a_base[i] = ((n * P.H + a_ih0[i]) * P.W + a_iw0[i]) * P.C;
+            a_base[i] = n * (int)P.in_sN + (a_ih0[i] * P.W + a_iw0[i]) * P.C;
         } else {
             a_ih0[i] = -0x40000000;                   // never valid
             a_iw0[i] = 0;
@@ -229,6 +230,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += bias[e];
+            const bool mask_first = (L.flags & 1) != 0;
+            if (P.mask && mask_first) {
+                const unsigned short* mp = P.mask + oo + k0;
+                for (int e = 0; e < nvalid; ++e) v[e] = bf16_to_f32(mp[e]) > 0.0f ? v[e] : 0.0f;
+            }
             if (P.addend) {
                 const unsigned short* ap = P.addend + s_addoff[row] + k0;
                 if (nvalid == 8) {
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = activate(v[e], L.act);
-            if (P.mask) {
+            if (P.mask && !mask_first) {
                 const unsigned short* mp = P.mask + oo + k0;
                 if (nvalid == 8) {
                     const s8v a = *reinterpret_cast<const s8v*>(mp);
@@ -292,7 +298,8 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
         MI355_REQUIRE(s.C == C && C > 0 && C % 8 == 0, "conv_gather: C must be a multiple of 8 and equal across problems");
         MI355_REQUIRE(s.N > 0 && s.H > 0 && s.W > 0 && s.P > 0 && s.Q > 0, "conv_gather: problem %d bad dims", i);
         MI355_REQUIRE(s.TR >= 0 && s.TS >= 0 && s.add_shift >= 0, "conv_gather: bad taps");
-        const long long in_bytes = (long long)s.N * s.H * s.W * s.C * 2;
+        const long long in_sN = s.in_sN ? s.in_sN : (long long)s.H * s.W * s.C;
+        const long long in_bytes = ((long long)(s.N - 1) * in_sN + (long long)s.H * s.W * s.C) * 2;
         MI355_REQUIRE(in_bytes < 0x7fffffffLL, "conv_gather: input tensor >= 2 GiB");
         MI355_REQUIRE((long long)s.N * s.P * s.Q < 0x7fffffffLL, "conv_gather: M too large");
         MI355_REQUIRE(((uintptr_t)s.in & 15) == 0 && ((uintptr_t)s.out & 15) == 0, "conv_gather: alignment");
@@ -305,6 +312,7 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
         d.out_mh = s.out_mh; d.out_oh = s.out_oh; d.out_mw = s.out_mw; d.out_ow = s.out_ow;
         d.out_sN = s.out_sN; d.out_sH = s.out_sH; d.out_sW = s.out_sW;
         d.add_sN = s.add_sN; d.add_sH = s.add_sH; d.add_sW = s.add_sW; d.add_shift = s.add_shift;
+        d.in_sN = in_sN;
         d.M = s.N * s.P * s.Q;
         d.in_bytes = (int)in_bytes;
         d.tile_begin = tiles;
@@ -316,7 +324,7 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
     MI355_REQUIRE(((uintptr_t)in.weight & 15) == 0, "conv_gather: weight alignment");
     L.w = (const unsigned short*)in.weight;
     L.bias = in.bias;
-    L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.act = in.act; L.out_f32 = in.out_f32;
+    L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.act = in.act; L.out_f32 = in.out_f32; L.flags = in.flags;
     L.n_tiles = (int)cdiv(in.K, BN);
     L.w_bytes = (int)w_bytes;
     const long long grid = (long long)tiles * L.n_tiles;

@@ -51,6 +51,7 @@ struct WProb {
     int r0, rs, s0, ss, S;
     int M, in_bytes, dy_bytes;
     int chunk_begin;
+    int in_sN, dy_sN;
     FastDiv dPQ, dQ;
 };
 
@@ -102,19 +103,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
         for (int i = 0; i < 4; ++i) {
             const int m = m_begin + step * RM + srow + 16 * i;
             const bool mok = m < m_end;
-            const unsigned offy = (mok && ky_ok) ? (unsigned)(m * L.K + ky) * 2u : OOB_OFFSET;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (LDS_PTR(void))(sy + (i * 256 + wv * 64) * 16),
-                                                     16, offy, 0, 0, 0);
-            unsigned offx = OOB_OFFSET;
-            if (mok && cx_ok) {
+            unsigned offy = OOB_OFFSET, offx = OOB_OFFSET;
+            if (mok) {
                 const unsigned n = fdiv((unsigned)m, P.dPQ);
                 const unsigned rem = (unsigned)m - n * (unsigned)(P.P * P.Q);
+                if (ky_ok) offy = (unsigned)((int)n * P.dy_sN + (int)rem * L.K + ky) * 2u;
                 const unsigned p = fdiv(rem, P.dQ);
                 const unsigned q = rem - p * (unsigned)P.Q;
                 const int ih = (int)p * P.sh + dh, iw = (int)q * P.sw + dw;
-                if ((unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W)
-                    offx = (unsigned)((((int)n * P.H + ih) * P.W + iw) * P.C + cx) * 2u;
+                if (cx_ok && (unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W)
+                    offx = (unsigned)((int)n * P.in_sN + (ih * P.W + iw) * P.C + cx) * 2u;
             }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (LDS_PTR(void))(sy + (i * 256 + wv * 64) * 16),
+                                                     16, offy, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_PTR(void))(sx + (i * 256 + wv * 64) * 16),
                                                      16, offx, 0, 0, 0);
         }
@@ -207,9 +208,11 @@ extern "C" int mi355_conv_wgrad(const Mi355ConvLaunch* launch, float* dw, int sp
         const Mi355ConvProblem& s = in.prob[i];
         MI355_REQUIRE(s.in && s.out, "conv_wgrad: problem %d null in/dy", i);
         MI355_REQUIRE(s.C == C && C % 8 == 0 && s.TR * s.TS == ntaps, "conv_wgrad: C%%8, taps equal across problems");
-        const long long in_bytes = (long long)s.N * s.H * s.W * s.C * 2;
+        const long long in_sN = s.in_sN ? s.in_sN : (long long)s.H * s.W * s.C;
+        const long long dy_sN = s.out_sN ? s.out_sN : (long long)s.P * s.Q * in.K;
+        const long long in_bytes = ((long long)(s.N - 1) * in_sN + (long long)s.H * s.W * s.C) * 2;
         const long long M = (long long)s.N * s.P * s.Q;
-        const long long dy_bytes = M * in.K * 2;
+        const long long dy_bytes = ((long long)(s.N - 1) * dy_sN + (long long)s.P * s.Q * in.K) * 2;
         MI355_REQUIRE(in_bytes < 0x7fffffffLL && dy_bytes < 0x7fffffffLL && M > 0, "conv_wgrad: tensor >= 2 GiB");
         MI355_REQUIRE(((uintptr_t)s.in & 15) == 0 && ((uintptr_t)s.out & 15) == 0, "conv_wgrad: alignment");
         WProb& d = L.p[i];
@@ -218,6 +221,7 @@ extern "C" int mi355_conv_wgrad(const Mi355ConvLaunch* launch, float* dw, int sp
         d.TR = s.TR; d.TS = s.TS; d.dh0 = s.dh0; d.dhs = s.dhs; d.dw0 = s.dw0; d.dws = s.dws;
         d.r0 = s.r0; d.rs = s.rs; d.s0 = s.s0; d.ss = s.ss; d.S = s.S;
         d.M = (int)M; d.in_bytes = (int)in_bytes; d.dy_bytes = (int)dy_bytes;
+        d.in_sN = (int)in_sN; d.dy_sN = (int)dy_sN;
         d.dPQ = make_fastdiv((unsigned)(s.P * s.Q));
         d.dQ = make_fastdiv((unsigned)s.Q);
         d.chunk_begin = chunks;

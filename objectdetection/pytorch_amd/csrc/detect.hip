@@ -389,7 +389,8 @@ __global__ __launch_bounds__(FL_TILE) void focal_bwd_kernel(
     const float* __restrict__ annot, const int32_t* __restrict__ argmax,
     const int8_t* __restrict__ state, const int32_t* __restrict__ num_pos,
     const float* __restrict__ grad_losses, int B, int A, int C, int M, float alpha,
-    void* __restrict__ grad_cls, void* __restrict__ grad_reg) {
+    void* __restrict__ grad_cls, void* __restrict__ grad_reg, int cell_anchors, int cls_pitch,
+    int cell_pitch) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* gt = smem;
     __shared__ int s_state[FL_TILE];
@@ -431,7 +432,14 @@ __global__ __launch_bounds__(FL_TILE) void focal_bwd_kernel(
             ushort4 o;
             o.x = f32_to_bf16(g4[0]); o.y = f32_to_bf16(g4[1]);
             o.z = f32_to_bf16(g4[2]); o.w = f32_to_bf16(g4[3]);
-            reinterpret_cast<ushort4*>(grad_reg)[(size_t)b * A + a] = o;
+            if (cell_anchors > 0) {
+                const int cell = a / cell_anchors, j = a - cell * cell_anchors;
+                unsigned short* dst = reinterpret_cast<unsigned short*>(grad_reg) +
+                                      ((size_t)b * (A / cell_anchors) + cell) * cell_pitch + j * 4;
+                dst[0] = o.x; dst[1] = o.y; dst[2] = o.z; dst[3] = o.w;
+            } else {
+                reinterpret_cast<ushort4*>(grad_reg)[(size_t)b * A + a] = o;
+            }
         }
     }
     s_state[tid] = st;
@@ -479,6 +487,21 @@ __global__ __launch_bounds__(FL_TILE) void focal_bwd_kernel(
             float* o = reinterpret_cast<float*>(grad_cls) + tbase;
             if (VEC == 4) reinterpret_cast<float4*>(o)[i] = make_float4(g[0], g[1 % VEC], g[2 % VEC], g[3 % VEC]);
             else o[i] = g[0];
+        } else if (cell_anchors > 0) {
+            // NHWC head-gradient rows: (cell, anchor-in-cell, class) with a padded cell pitch
+            const int aa = a0 + e0 / C, cc = e0 - (e0 / C) * C;
+            const int cell = aa / cell_anchors;
+            unsigned short* o = reinterpret_cast<unsigned short*>(grad_cls) +
+                                ((size_t)b * (A / cell_anchors) + cell) * cls_pitch +
+                                (size_t)(aa - cell * cell_anchors) * C + cc;
+            if (VEC == 4) {
+                ushort4 w;
+                w.x = f32_to_bf16(g[0]); w.y = f32_to_bf16(g[1 % VEC]);
+                w.z = f32_to_bf16(g[2 % VEC]); w.w = f32_to_bf16(g[3 % VEC]);
+                *reinterpret_cast<ushort4*>(o) = w;
+            } else {
+                o[0] = f32_to_bf16(g[0]);
+            }
         } else {
             unsigned short* o = reinterpret_cast<unsigned short*>(grad_cls) + tbase;
             if (VEC == 4) {
@@ -497,12 +520,17 @@ extern "C" int mi355_focal_loss_bwd(const float* cls, const float* reg, const fl
                                     const float* annot, const int32_t* argmax, const int8_t* state,
                                     const int32_t* num_pos, const float* grad_losses, int B, int A,
                                     int C, int M, float alpha, int grad_mode, void* grad_cls,
-                                    void* grad_reg, void* stream) {
+                                    void* grad_reg, int cell_anchors, int cls_cell_pitch,
+                                    int reg_cell_pitch, void* stream) {
     MI355_REQUIRE(cls && reg && anchors && argmax && state && num_pos && grad_losses && grad_cls &&
                   grad_reg, "focal_loss_bwd: null pointer");
     MI355_REQUIRE(B > 0 && B <= 65535 && A > 0 && C > 0 && M >= 0, "focal_loss_bwd: bad shape");
     MI355_REQUIRE((int64_t)M * 24 <= 96 * 1024, "focal_loss_bwd: M too large");
     MI355_REQUIRE(grad_mode == 0 || grad_mode == 1, "focal_loss_bwd: grad_mode");
+    MI355_REQUIRE(cell_anchors == 0 || (grad_mode == 1 && A % cell_anchors == 0 &&
+                                        reg_cell_pitch >= cell_anchors * 4 && reg_cell_pitch % 4 == 0 &&
+                                        cls_cell_pitch >= cell_anchors * C && cls_cell_pitch % 4 == 0),
+                  "focal_loss_bwd: bad cell layout");
     const int nblk = (int)cdiv(A, FL_TILE);
     dim3 grid(nblk, B), block(FL_TILE);
     size_t lds = (size_t)(M > 0 ? M : 1) * 24;
@@ -510,7 +538,7 @@ extern "C" int mi355_focal_loss_bwd(const float* cls, const float* reg, const fl
 #define LAUNCH_BWD(V, MD)                                                                        \
     hipLaunchKernelGGL((focal_bwd_kernel<V, MD>), grid, block, lds, (hipStream_t)stream, cls,    \
                        reg, (const float4*)anchors, annot, argmax, state, num_pos, grad_losses,  \
-                       B, A, C, M, alpha, grad_cls, grad_reg)
+                       B, A, C, M, alpha, grad_cls, grad_reg, cell_anchors, cls_cell_pitch, reg_cell_pitch)
     if (vec4) { if (grad_mode == 0) LAUNCH_BWD(4, 0); else LAUNCH_BWD(4, 1); }
     else      { if (grad_mode == 0) LAUNCH_BWD(1, 0); else LAUNCH_BWD(1, 1); }
 #undef LAUNCH_BWD

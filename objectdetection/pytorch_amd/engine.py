@@ -1,0 +1,568 @@
+"""Static launch plans for the RetinaNet hot path (MI355X-first: no tracing compiler, no per-op
+autograd graph).
+
+A `RetinaPlan` is built once per (batch, height, width): it owns every activation / gradient
+buffer in HBM (persistent, sized for the 288 GB part) and a flat list of pre-marshalled C-ABI
+launches (`ctypes` structs built once).  A training step is then
+
+    prep (frozen-BN fold + bf16 weight shadows)  ->  forward launches  ->  fused loss
+    ->  loss backward (writes bf16 d/dlogit)     ->  backward launches ->  parameter grads
+
+with no Python tensor math and no host<->device sync in between, so the whole step can also be
+captured in a hipGraph (`RetinaPlan.capture`).
+
+Mirrors the forward of architectures/retinanet.py:272-295 and its autograd backward.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops_conv, ops_detect
+from ._lib import c_f32, c_i64, c_int, c_vp, ptr
+from .ops_conv import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvLaunch, dgrad_problems, fwd_problem,
+                       out_hw, pick_split_rows)
+
+
+def _ceil8(v):
+    return (v + 7) // 8 * 8
+
+
+class LayerSpec(object):
+    """One conv (+ optional frozen BN) of the network and its device-side shadows."""
+
+    def __init__(self, name, conv, bn=None):
+        self.name, self.conv, self.bn = name, conv, bn
+        self.K, self.C, self.R, self.S = conv.weight.shape
+        self.stride, self.pad = conv.stride[0], conv.padding[0]
+        self.Cpad, self.Kpad = _ceil8(self.C), _ceil8(self.K)
+        self.T = self.R * self.S
+        self.need_dgrad = True
+        # filled by the plan
+        self.w_fwd = self.w_dgr = self.scale = self.shift = None
+        self.G = self.colsum = None
+        self.direct = False        # wgrad writes straight into the parameter-gradient arena
+
+    @property
+    def bias_tensor(self):
+        return self.shift if self.bn is not None else self.conv.bias
+
+
+class RetinaPlan(object):
+    def __init__(self, model, B, H, W, device):
+        if H % 32 or W % 32:
+            # the reference's FPN (nn.Upsample x2 + add, retinanet.py:52-61) needs this too;
+            # its Resizer pads to multiples of 32 (datasettool/dataloader.py:887-892)
+            raise ValueError('RetinaNet input must be a multiple of 32, got %dx%d' % (H, W))
+        self.model, self.B, self.H, self.W, self.dev = model, B, H, W, device
+        self.lib = _lib.lib()
+        self.keep = []                 # ctypes objects referenced by the steps
+        self.prep_steps, self.fwd_steps, self.bwd_steps, self.pgrad_steps = [], [], [], []
+        self.bufs = []
+        self.fwd_launches = []         # (spec, [(n, p, q) per problem]) for FLOP accounting
+        self.last_arena = 0
+        self.num_classes = model.classificationModel.num_classes
+        self.A_cell = model.anchors.num_anchors_per_cell
+        self._collect_layers()
+        self._alloc_params()
+        self._build_prep()
+        self._build_forward()
+        self._build_backward()
+        self._param_ptrs = self._ptr_signature()
+
+    # ------------------------------------------------------------------ bookkeeping
+    def new(self, shape, dtype=torch.bfloat16, zero=False):
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
+        self.bufs.append(t)
+        return t
+
+    def _ptr_signature(self):
+        sig = [p.data_ptr() for p in self.model.parameters()]
+        sig += [b.data_ptr() for b in self.model.buffers()]
+        return sig
+
+    def stale(self):
+        return self._param_ptrs != self._ptr_signature()
+
+    def _step(self, lst, name, *args):
+        self.keep.append(args)
+        lst.append((getattr(self.lib, name), args, name))
+
+    def _run(self, steps, stream):
+        s = c_vp(stream)
+        for fn, args, name in steps:
+            rc = fn(*args, s)
+            if rc:
+                raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, self.lib.mi355_last_error().decode()))
+
+    # ------------------------------------------------------------------ layers / parameters
+    def _collect_layers(self):
+        m = self.model
+        self.specs = []
+
+        def add(name, conv, bn=None):
+            s = LayerSpec(name, conv, bn)
+            self.specs.append(s)
+            return s
+
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Conv2d) and not mod.weight.permute(0, 2, 3, 1).is_contiguous():
+                raise _lib.Mi355Error('conv weights must be KRSC (channels_last) in memory: call '
+                                      'model._channels_last_params()')
+        self.stem = add('conv1', m.conv1, m.bn1)
+        self.stem.need_dgrad = False
+        self.blocks = []
+        for li, layer in enumerate([m.layer1, m.layer2, m.layer3, m.layer4]):
+            for bi, blk in enumerate(layer):
+                pre = 'layer%d.%d' % (li + 1, bi)
+                rec = {'kind': 'bottleneck' if hasattr(blk, 'conv3') else 'basic'}
+                rec['c1'] = add(pre + '.conv1', blk.conv1, blk.bn1)
+                rec['c2'] = add(pre + '.conv2', blk.conv2, blk.bn2)
+                if rec['kind'] == 'bottleneck':
+                    rec['c3'] = add(pre + '.conv3', blk.conv3, blk.bn3)
+                rec['ds'] = (add(pre + '.downsample', blk.downsample[0], blk.downsample[1])
+                             if blk.downsample is not None else None)
+                rec['stage_end'] = (bi == len(layer) - 1)
+                rec['stage'] = li
+                self.blocks.append(rec)
+        f = m.fpn
+        self.fpn = {n: add('fpn.' + n, getattr(f, n)) for n in
+                    ('P5_1', 'P5_2', 'P4_1', 'P4_2', 'P3_1', 'P3_2', 'P6', 'P7_2')}
+        self.reg_tower = [add('regressionModel.conv%d' % i, getattr(m.regressionModel, 'conv%d' % i))
+                          for i in range(1, 5)]
+        self.reg_out = add('regressionModel.output', m.regressionModel.output)
+        self.cls_tower = [add('classificationModel.conv%d' % i, getattr(m.classificationModel, 'conv%d' % i))
+                          for i in range(1, 5)]
+        self.cls_out = add('classificationModel.output', m.classificationModel.output)
+
+    def _alloc_params(self):
+        """bf16 shadow arena, folded-BN arena, raw-wgrad scratch arena, and the flat parameter-
+        gradient arena (one tensor: a single RCCL all-reduce covers every gradient)."""
+        params = list(self.model.parameters())
+        self.params = params
+        offs, total = {}, 0
+        for p in params:
+            offs[id(p)] = total
+            total += p.numel()
+        self.grad_offsets = offs
+        self.grad_numel = total
+        self.grad_arenas = [torch.zeros(total, dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.active = 0
+        shadow = sum(s.K * s.T * s.Cpad + (s.C * s.T * s.Kpad if s.need_dgrad else 0) for s in self.specs)
+        self.shadow = self.new((shadow + 64,), torch.bfloat16, zero=True)
+        nbn = sum(2 * s.K for s in self.specs if s.bn is not None)
+        self.bnbuf = self.new((max(nbn, 1),), torch.float32)
+        so, bo = 0, 0
+        scratch = 0
+        for s in self.specs:
+            n = s.K * s.T * s.Cpad
+            s.w_fwd = self.shadow[so:so + n].view(s.K, s.T, s.Cpad)
+            so += (n + 7) // 8 * 8
+            if s.need_dgrad:
+                n = s.C * s.T * s.Kpad
+                s.w_dgr = self.shadow[so:so + n].view(s.C, s.T, s.Kpad)
+                so += (n + 7) // 8 * 8
+            if s.bn is not None:
+                s.scale = self.bnbuf[bo:bo + s.K]
+                s.shift = self.bnbuf[bo + s.K:bo + 2 * s.K]
+                bo += 2 * s.K
+            s.direct = (s.bn is None and s.Cpad == s.C and s.Kpad == s.K)
+            if not s.direct:
+                scratch += s.Kpad * s.T * s.Cpad + s.Kpad
+        self.scratch = self.new((max(scratch, 1),), torch.float32, zero=True)
+        self._carve_grads(0)
+
+    def grad_view(self, p, arena):
+        off = self.grad_offsets[id(p)]
+        flat = self.grad_arenas[arena][off:off + p.numel()]
+        if p.dim() == 4:        # same KRSC memory order and the SAME strides as the parameter
+            return flat.as_strided(p.shape, p.stride())
+        return flat.view(p.shape)
+
+    def _carve_grads(self, arena):
+        """Point every layer's wgrad / colsum target at `arena` (or the scratch arena)."""
+        so = 0
+        for s in self.specs:
+            w = s.conv.weight
+            if s.direct:
+                off = self.grad_offsets[id(w)]
+                s.G = self.grad_arenas[arena][off:off + w.numel()]
+                boff = self.grad_offsets[id(s.conv.bias)]
+                s.colsum = self.grad_arenas[arena][boff:boff + s.K]
+            else:
+                n = s.Kpad * s.T * s.Cpad
+                s.G = self.scratch[so:so + n]
+                s.colsum = self.scratch[so + n:so + n + s.Kpad]
+                so += n + s.Kpad
+
+    # ------------------------------------------------------------------ prep (per step)
+    def _build_prep(self):
+        for s in self.specs:
+            w = s.conv.weight
+            if s.bn is not None:
+                bn = s.bn
+                self._step(self.prep_steps, 'mi355_bn_fold', ptr(bn.weight), ptr(bn.bias),
+                           ptr(bn.running_mean), ptr(bn.running_var), c_f32(bn.eps), c_int(s.K),
+                           ptr(s.scale), ptr(s.shift))
+            sk, sc, sr, ss = w.stride()
+            self._step(self.prep_steps, 'mi355_prep_weight', ptr(w), c_i64(sk), c_i64(sc), c_i64(sr),
+                       c_i64(ss), c_int(s.K), c_int(s.C), c_int(s.R), c_int(s.S), c_int(s.Cpad),
+                       ptr(s.scale), ptr(s.w_fwd), ptr(s.w_dgr))
+
+    # ------------------------------------------------------------------ launch builders
+    def _gather(self, lst, problems, weight, K, T, bias=None, act=ACT_NONE, out_f32=False, flags=0):
+        assert len(problems) <= ops_conv.MAX_PROBLEMS
+        L = ConvLaunch()
+        for j, pr in enumerate(problems):
+            L.prob[j] = pr
+        L.nprob, L.K, L.weight, L.T = len(problems), K, weight.data_ptr(), T
+        L.act, L.bias, L.out_f32, L.flags = act, (0 if bias is None else bias.data_ptr()), int(out_f32), flags
+        self._step(lst, 'mi355_conv_gather', ctypes.byref(L))
+        self.keep.append(L)
+
+    def _wgrad(self, problems, spec, rows):
+        L = ConvLaunch()
+        for j, pr in enumerate(problems):
+            L.prob[j] = pr
+        L.nprob, L.K, L.T = len(problems), spec.Kpad, spec.T
+        tiles = spec.T * (-(-spec.Kpad // 128)) * (-(-spec.Cpad // 128))
+        split = pick_split_rows(rows, tiles)
+        self._step(self.bwd_steps, 'mi355_conv_wgrad', ctypes.byref(L), ptr(spec.G), c_int(split))
+        self.keep.append(L)
+        spec._wgrad_launch = L
+
+    def conv(self, spec, x, act=ACT_NONE, addend=None, add_shift=0):
+        N, H, W, C = x.shape
+        assert C == spec.Cpad, (spec.name, C, spec.Cpad)
+        P, Q = out_hw(H, W, spec.R, spec.stride, spec.pad)
+        out = self.new((N, P, Q, spec.K))
+        pr = fwd_problem(x, out.data_ptr(), spec.R, spec.S, spec.stride, spec.pad, K=spec.K,
+                         addend=addend, add_shift=add_shift)
+        self._gather(self.fwd_steps, [pr], spec.w_fwd, spec.K, spec.T, bias=spec.bias_tensor, act=act)
+        self.fwd_launches.append((spec, [(N, P, Q)]))
+        return out
+
+    def conv_bwd(self, spec, x, dy, dx=None, addend=None, mask=None, mask_first=False, dgrad=True):
+        """wgrad (+ column sums) of `spec` and, optionally, its data gradient into `dx`."""
+        N, H, W, C = x.shape
+        pr = fwd_problem(x, dy.data_ptr(), spec.R, spec.S, spec.stride, spec.pad, K=spec.Kpad)
+        self._wgrad([pr], spec, N * pr.P * pr.Q)
+        self._step(self.bwd_steps, 'mi355_colsum_bf16', ptr(dy), c_i64(dy.numel() // dy.shape[-1]),
+                   c_int(dy.shape[-1]), ptr(spec.colsum))
+        if not dgrad:
+            return None
+        if dx is None:
+            dx = self.new((N, H, W, spec.Cpad))
+        probs = dgrad_problems(dy, dx.data_ptr(), H, W, spec.Cpad, spec.R, spec.S, spec.stride, spec.pad,
+                               addend=addend, mask=mask)
+        self._gather(self.bwd_steps, probs, spec.w_dgr, spec.Cpad, spec.T, flags=1 if mask_first else 0)
+        return dx
+
+    # ------------------------------------------------------------------ forward
+    def _build_forward(self):
+        B, H, W = self.B, self.H, self.W
+        self.img_nhwc = self.new((B, H, W, 8))
+        x = self.conv(self.stem, self.img_nhwc, ACT_RELU)
+        self.c1 = x
+        P, Q = (x.shape[1] - 1) // 2 + 1, (x.shape[2] - 1) // 2 + 1
+        self.mp = self.new((B, P, Q, 64))
+        self.mp_idx = self.new((B, P, Q, 64), torch.int8)
+        self._step(self.fwd_steps, 'mi355_maxpool3x3s2_fwd', ptr(x), ptr(self.mp), ptr(self.mp_idx),
+                   c_int(B), c_int(x.shape[1]), c_int(x.shape[2]), c_int(64))
+        x = self.mp
+        feats = []
+        for rec in self.blocks:
+            rec['x'] = x
+            if rec['kind'] == 'bottleneck':
+                rec['a'] = self.conv(rec['c1'], x, ACT_RELU)
+                rec['b'] = self.conv(rec['c2'], rec['a'], ACT_RELU)
+                res = self.conv(rec['ds'], x) if rec['ds'] is not None else x
+                rec['out'] = self.conv(rec['c3'], rec['b'], ACT_RELU, addend=res)
+            else:
+                rec['a'] = self.conv(rec['c1'], x, ACT_RELU)
+                res = self.conv(rec['ds'], x) if rec['ds'] is not None else x
+                rec['out'] = self.conv(rec['c2'], rec['a'], ACT_RELU, addend=res)
+            x = rec['out']
+            if rec['stage_end']:
+                feats.append(x)
+        c3, c4, c5 = feats[1], feats[2], feats[3]
+        self.c3, self.c4, self.c5 = c3, c4, c5
+        f = self.fpn
+        self.p5lat = self.conv(f['P5_1'], c5)
+        self.p5 = self.conv(f['P5_2'], self.p5lat)
+        self.p4lat = self.conv(f['P4_1'], c4, addend=self.p5lat, add_shift=1)
+        self.p4 = self.conv(f['P4_2'], self.p4lat)
+        self.p3lat = self.conv(f['P3_1'], c3, addend=self.p4lat, add_shift=1)
+        self.p3 = self.conv(f['P3_2'], self.p3lat)
+        self.p6 = self.conv(f['P6'], c5)
+        self.p6relu = self.new(tuple(self.p6.shape))
+        self._step(self.fwd_steps, 'mi355_relu_mask_bf16', ptr(self.p6), ptr(self.p6), ptr(self.p6relu),
+                   c_i64(self.p6.numel()))
+        self.p7 = self.conv(f['P7_2'], self.p6relu)
+        self.levels = [self.p3, self.p4, self.p5, self.p6, self.p7]
+        self.cells = [t.shape[1] * t.shape[2] for t in self.levels]
+        self.cell_off = [sum(self.cells[:i]) for i in range(5)]
+        self.ncells = sum(self.cells)
+        self.A = self.ncells * self.A_cell
+        C = self.num_classes
+        self.reg_t = self._tower_fwd(self.reg_tower)
+        self.cls_t = self._tower_fwd(self.cls_tower)
+        self.reg = self.new((B, self.A, 4), torch.float32)
+        self.cls = self.new((B, self.A, C), torch.float32)
+        self._head_out_fwd(self.reg_out, self.reg_t[-1], self.reg, 4 * self.A_cell, ACT_NONE)
+        self._head_out_fwd(self.cls_out, self.cls_t[-1], self.cls, C * self.A_cell, ACT_SIGMOID)
+        # loss state
+        self.losses = self.new((2,), torch.float32)
+        self.argmax = self.new((B, self.A), torch.int32)
+        self.state = self.new((B, self.A), torch.int8)
+        self.num_pos = self.new((B,), torch.int32)
+        nb = ctypes.c_int64()
+        _lib.call('mi355_focal_loss_workspace_bytes', c_int(B), c_int(self.A), c_int(C), c_int(1),
+                  ctypes.byref(nb))
+        self.loss_ws = self.new((nb.value,), torch.uint8)
+        self.loss_ws_bytes = nb.value
+        self.glosses = self.new((2,), torch.float32)
+
+    def _level_views(self, buf):
+        """Per-level NHWC views of a level-major buffer [sum_l B*h_l*w_l, 256]."""
+        views, off = [], 0
+        for lv in self.levels:
+            n = self.B * lv.shape[1] * lv.shape[2]
+            views.append(buf[off:off + n].view(self.B, lv.shape[1], lv.shape[2], buf.shape[1]))
+            off += n
+        return views
+
+    def _tower_fwd(self, tower):
+        """4 x (conv3x3 + ReLU) with shared weights over the 5 levels: ONE grouped launch per conv
+        (retinanet.py:92-104 runs 5 launch sets per conv)."""
+        rows = self.B * self.ncells
+        xs = self.levels
+        outs = []
+        for spec in tower:
+            buf = self.new((rows, 256))
+            ys = self._level_views(buf)
+            probs = [fwd_problem(x, y.data_ptr(), 3, 3, 1, 1, K=256) for x, y in zip(xs, ys)]
+            self._gather(self.fwd_steps, probs, spec.w_fwd, 256, 9, bias=spec.conv.bias, act=ACT_RELU)
+            self.fwd_launches.append((spec, [(x.shape[0], x.shape[1], x.shape[2]) for x in xs]))
+            outs.append(ys)
+            xs = ys
+        return outs
+
+    def _head_out_fwd(self, spec, xs, out, kout, act):
+        """Output conv writing fp32 straight into the [B, A, .] layout of retinanet.py:108-115 /
+        :163-178 (NHWC is already (y, x, anchor, class) order: no permute/cat pass)."""
+        per_img = self.ncells * kout
+        probs = []
+        for x, off in zip(xs, self.cell_off):
+            w = x.shape[2]
+            probs.append(fwd_problem(x, out.data_ptr() + 4 * off * kout, 3, 3, 1, 1,
+                                     out_strides=(per_img, w * kout, kout), K=kout))
+        self._gather(self.fwd_steps, probs, spec.w_fwd, kout, 9, bias=spec.conv.bias, act=act, out_f32=True)
+        self.fwd_launches.append((spec, [(x.shape[0], x.shape[1], x.shape[2]) for x in xs]))
+
+    # ------------------------------------------------------------------ backward
+    def _build_backward(self):
+        B, C = self.B, self.num_classes
+        kc = self.cls_out.Kpad                     # 720 (9 anchors x 80 classes), padded to 8
+        kr = self.reg_out.Kpad                     # 40 (36 padded)
+        self.gcls = self.new((B, self.ncells, kc), zero=True)       # bf16 d/dlogit, cell rows
+        self.greg = self.new((B, self.ncells, kr), zero=True)       # bf16, padded pitch
+        self.cls_pitch, self.reg_pitch = kc, kr
+        # ---- heads: output convs, then the towers (levels grouped), feature grads accumulated
+        g_feat = [self.new(tuple(lv.shape)) for lv in self.levels]
+        self._head_bwd(self.reg_out, self.reg_tower, self.reg_t, self.greg, kr, g_feat, first=True)
+        self._head_bwd(self.cls_out, self.cls_tower, self.cls_t, self.gcls, kc, g_feat, first=False)
+        g_p3, g_p4, g_p5, g_p6, g_p7 = g_feat
+        f = self.fpn
+        # ---- FPN (retinanet.py:48-69 reversed)
+        self.conv_bwd(f['P7_2'], self.p6relu, g_p7, dx=g_p6, addend=g_p6, mask=self.p6, mask_first=True)
+        g_c5 = self.conv_bwd(f['P6'], self.c5, g_p6)
+        g_p5lat = self.conv_bwd(f['P5_2'], self.p5lat, g_p5)
+        g_p4lat = self.conv_bwd(f['P4_2'], self.p4lat, g_p4)
+        g_p3lat = self.conv_bwd(f['P3_2'], self.p3lat, g_p3)
+        self._sumpool(g_p3lat, g_p4lat)
+        g_c3 = self.conv_bwd(f['P3_1'], self.c3, g_p3lat)
+        self._sumpool(g_p4lat, g_p5lat)
+        g_c4 = self.conv_bwd(f['P4_1'], self.c4, g_p4lat)
+        # c5 has no later consumer: finish it here (sum of P6 and P5_1 grads, ReLU of layer4)
+        self.conv_bwd(f['P5_1'], self.c5, g_p5lat, dx=g_c5, addend=g_c5, mask=self.c5)
+        # ---- backbone, last block first.  g = gradient w.r.t. the block output's pre-ReLU sum.
+        extra = {2: g_c4, 1: g_c3}                 # raw FPN-lateral grads of the stage outputs
+        g = g_c5
+        for i in range(len(self.blocks) - 1, -1, -1):
+            rec = self.blocks[i]
+            x = rec['x']
+            first_block = (i == 0)
+            x_extra = None
+            if i > 0 and self.blocks[i - 1]['stage_end'] and self.blocks[i - 1]['stage'] in extra:
+                x_extra = extra[self.blocks[i - 1]['stage']]
+            mask_x = None if first_block else x    # x = max-pool output for the very first block
+            if rec['kind'] == 'bottleneck':
+                g_b = self.conv_bwd(rec['c3'], rec['b'], g, mask=rec['b'])
+                g_a = self.conv_bwd(rec['c2'], rec['a'], g_b, mask=rec['a'])
+                last = rec['c1']
+            else:
+                g_a = self.conv_bwd(rec['c2'], rec['a'], g, mask=rec['a'])
+                last = rec['c1']
+            if rec['ds'] is not None:
+                res_g = self.conv_bwd(rec['ds'], x, g, dx=x_extra, addend=x_extra)
+            else:
+                assert x_extra is None
+                res_g = g
+            g = self.conv_bwd(last, x, g_a, addend=res_g, mask=mask_x)
+        # ---- stem: max-pool backward (+ ReLU mask of the stem output), wgrad only
+        g_c1 = self.new(tuple(self.c1.shape))
+        self._step(self.bwd_steps, 'mi355_maxpool3x3s2_bwd', ptr(g), ptr(self.mp_idx), ptr(g_c1),
+                   ptr(self.c1), c_int(B), c_int(self.c1.shape[1]), c_int(self.c1.shape[2]), c_int(64))
+        self.conv_bwd(self.stem, self.img_nhwc, g_c1, dgrad=False)
+        self._build_param_grads()
+
+    def _sumpool(self, src, dst):
+        N, H, W, C = src.shape
+        self._step(self.bwd_steps, 'mi355_sumpool2x2_bf16', ptr(src), ptr(dst), c_int(N), c_int(H),
+                   c_int(W), c_int(C), c_int(1))
+
+    def _head_bwd(self, out_spec, tower, acts, gout, kp, g_feat, first):
+        B = self.B
+        rows = B * self.ncells
+        # output conv: dy = gout viewed per level with the image stride of the [B, cells, kp] buffer
+        xs = acts[-1]
+        wprobs, dprobs = [], []
+        gbuf = self.new((rows, 256))
+        gys = self._level_views(gbuf)
+        for x, gy, off in zip(xs, gys, self.cell_off):
+            h, w = x.shape[1], x.shape[2]
+            dy_ptr = gout.data_ptr() + 2 * off * kp
+            pr = fwd_problem(x, dy_ptr, 3, 3, 1, 1, K=kp)
+            pr.out_sN = self.ncells * kp
+            wprobs.append(pr)
+            # dgrad: input = dy [B,h,w,kp] with batch stride, output = grad of the tower's last act
+            dp = ops_conv.ConvProblem()
+            dp.in_, dp.out, dp.mask = dy_ptr, gy.data_ptr(), x.data_ptr()
+            dp.N, dp.H, dp.W, dp.C, dp.P, dp.Q, dp.sh, dp.sw = B, h, w, kp, h, w, 1, 1
+            dp.TR, dp.TS, dp.dh0, dp.dhs, dp.dw0, dp.dws = 3, 3, 1, -1, 1, -1
+            dp.r0, dp.rs, dp.s0, dp.ss, dp.S = 0, 1, 0, 1, 3
+            dp.out_mh, dp.out_oh, dp.out_mw, dp.out_ow = 1, 0, 1, 0
+            dp.out_sN, dp.out_sH, dp.out_sW = h * w * 256, w * 256, 256
+            dp.in_sN = self.ncells * kp
+            dprobs.append(dp)
+        self._wgrad(wprobs, out_spec, rows)
+        self._step(self.bwd_steps, 'mi355_colsum_bf16', ptr(gout), c_i64(rows), c_int(kp), ptr(out_spec.colsum))
+        self._gather(self.bwd_steps, dprobs, out_spec.w_dgr, 256, 9)
+        # tower convs 4..1
+        for li in range(3, -1, -1):
+            spec = tower[li]
+            xs = acts[li - 1] if li > 0 else self.levels
+            wprobs = [fwd_problem(x, gy.data_ptr(), 3, 3, 1, 1, K=256) for x, gy in zip(xs, gys)]
+            self._wgrad(wprobs, spec, rows)
+            self._step(self.bwd_steps, 'mi355_colsum_bf16', ptr(gbuf), c_i64(rows), c_int(256), ptr(spec.colsum))
+            if li > 0:
+                nbuf = self.new((rows, 256))
+                nys = self._level_views(nbuf)
+                probs = []
+                for x, gy, ny in zip(xs, gys, nys):
+                    probs += dgrad_problems(gy, ny.data_ptr(), x.shape[1], x.shape[2], 256, 3, 3, 1, 1, mask=x)
+                self._gather(self.bwd_steps, probs, spec.w_dgr, 256, 9)
+                gbuf, gys = nbuf, nys
+            else:
+                probs = []
+                for x, gy, gf in zip(xs, gys, g_feat):
+                    probs += dgrad_problems(gy, gf.data_ptr(), x.shape[1], x.shape[2], 256, 3, 3, 1, 1,
+                                            addend=None if first else gf)
+                self._gather(self.bwd_steps, probs, spec.w_dgr, 256, 9)
+
+    def _build_param_grads(self):
+        """BN-folded layers (and padded ones): dW = G*scale, dgamma, dbeta from the raw wgrad."""
+        self.pgrad_args = []
+        for s in self.specs:
+            if s.direct:
+                continue
+            self.pgrad_args.append(s)
+
+    def _run_param_grads(self, arena, stream):
+        st = c_vp(stream)
+        for s in self.pgrad_args:
+            w = s.conv.weight
+            sk, sc, sr, ss = w.stride()
+            dW = self.grad_view(w, arena)
+            bn = s.bn
+            dgam = self.grad_view(bn.weight, arena) if bn is not None else None
+            dbet = (self.grad_view(bn.bias, arena) if bn is not None
+                    else (self.grad_view(s.conv.bias, arena) if s.conv.bias is not None else None))
+            rc = self.lib.mi355_conv_param_grads(
+                ptr(s.G), ptr(w), c_i64(sk), c_i64(sc), c_i64(sr), c_i64(ss), c_int(s.K), c_int(s.C),
+                c_int(s.R), c_int(s.S), c_int(s.Cpad), ptr(s.scale), ptr(s.colsum),
+                ptr(bn.running_mean if bn is not None else None),
+                ptr(bn.running_var if bn is not None else None),
+                c_f32(bn.eps if bn is not None else 0.0), ptr(dW), ptr(dgam), ptr(dbet), c_int(0), st)
+            if rc:
+                raise _lib.Mi355Error('conv_param_grads(%s): %s' % (s.name, self.lib.mi355_last_error().decode()))
+
+    # ------------------------------------------------------------------ execution
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def run_heads(self, img):
+        """prep + forward launches; fills self.cls / self.reg."""
+        st = self._stream()
+        img = img.contiguous()
+        if img.dtype != torch.float32:
+            img = img.float()
+        self._img_ref = img
+        rc = self.lib.mi355_nchw_to_nhwc_bf16(ptr(img), ptr(self.img_nhwc), c_int(self.B), c_int(3),
+                                              c_int(self.H), c_int(self.W), c_int(8), c_vp(st))
+        if rc:
+            raise _lib.Mi355Error('nchw_to_nhwc: %s' % self.lib.mi355_last_error().decode())
+        self._run(self.prep_steps, st)
+        self._run(self.fwd_steps, st)
+
+    def run_loss(self, anchors, annot):
+        annot = annot.contiguous().float()
+        self._annot = annot
+        self._anchors = anchors
+        M = annot.shape[1]
+        _lib.call('mi355_focal_loss_fwd', ptr(self.cls), ptr(self.reg), ptr(anchors), ptr(annot),
+                  c_int(self.B), c_int(self.A), c_int(self.num_classes), c_int(M),
+                  c_f32(ops_detect.NEG_THR), c_f32(ops_detect.POS_THR), c_f32(ops_detect.ALPHA),
+                  ptr(self.losses), ptr(self.argmax), ptr(self.state), ptr(self.num_pos),
+                  ptr(self.loss_ws), c_i64(self.loss_ws_bytes), c_vp(self._stream()))
+        return self.losses
+
+    def run_backward(self, g_cls, g_reg):
+        st = self._stream()
+        arena = self._arena_for_backward()
+        self.last_arena = arena
+        self.glosses[0:1].copy_(g_cls.reshape(1) if g_cls is not None else torch.zeros(1, device=self.dev))
+        self.glosses[1:2].copy_(g_reg.reshape(1) if g_reg is not None else torch.zeros(1, device=self.dev))
+        self.grad_arenas[arena].zero_()
+        self.scratch.zero_()
+        annot = self._annot
+        _lib.call('mi355_focal_loss_bwd', ptr(self.cls), ptr(self.reg), ptr(self._anchors), ptr(annot),
+                  ptr(self.argmax), ptr(self.state), ptr(self.num_pos), ptr(self.glosses),
+                  c_int(self.B), c_int(self.A), c_int(self.num_classes), c_int(annot.shape[1]),
+                  c_f32(ops_detect.ALPHA), c_int(1), ptr(self.gcls), ptr(self.greg),
+                  c_int(self.A_cell), c_int(self.cls_pitch), c_int(self.reg_pitch), c_vp(st))
+        self._run(self.bwd_steps if arena == 0 else self.bwd_steps_alt, st)
+        self._run_param_grads(arena, st)
+        return [self.grad_view(p, arena) if p.requires_grad else None for p in self.params]
+
+    def _arena_for_backward(self):
+        lo = self.grad_arenas[0].data_ptr()
+        hi = lo + self.grad_numel * 4
+        for p in self.params:
+            g = p.grad
+            if g is not None and lo <= g.data_ptr() < hi:
+                if not hasattr(self, 'bwd_steps_alt'):
+                    self._build_alt_backward()
+                return 1
+        return 0
+
+    def _build_alt_backward(self):
+        """Second copy of the backward launches targeting gradient arena 1 (used only when live
+        `.grad` tensors still alias arena 0, i.e. gradient accumulation without zero_grad)."""
+        main_steps, main_keep = self.bwd_steps, self.keep
+        self.bwd_steps = []
+        self._carve_grads(1)
+        self._build_backward()
+        self.bwd_steps_alt = self.bwd_steps
+        self.bwd_steps = main_steps
+        self._carve_grads(0)

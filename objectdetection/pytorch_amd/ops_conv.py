@@ -22,13 +22,13 @@ class ConvProblem(ctypes.Structure):
                 ('out_mh', c_int), ('out_oh', c_int), ('out_mw', c_int), ('out_ow', c_int),
                 ('out_sN', c_i64), ('out_sH', c_i64), ('out_sW', c_i64),
                 ('add_sN', c_i64), ('add_sH', c_i64), ('add_sW', c_i64),
-                ('add_shift', c_int), ('reserved', c_int)]
+                ('add_shift', c_int), ('reserved', c_int), ('in_sN', c_i64)]
 
 
 class ConvLaunch(ctypes.Structure):
     _fields_ = [('prob', ConvProblem * MAX_PROBLEMS), ('nprob', c_int), ('K', c_int),
                 ('weight', c_vp), ('T', c_int), ('act', c_int), ('bias', c_vp),
-                ('out_f32', c_int), ('reserved', c_int)]
+                ('out_f32', c_int), ('flags', c_int)]
 
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2

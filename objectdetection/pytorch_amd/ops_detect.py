@@ -79,7 +79,7 @@ def focal_loss_bwd(saved, argmax, state, num_pos, grad_losses, mode=0):
     grad_losses = _c(grad_losses)
     call('mi355_focal_loss_bwd', ptr(cls), ptr(reg), ptr(anchors), ptr(annot), ptr(argmax),
          ptr(state), ptr(num_pos), ptr(grad_losses), c_int(B), c_int(A), c_int(C), c_int(M),
-         c_f32(ALPHA), c_int(mode), ptr(gcls), ptr(greg), stream_of(cls))
+         c_f32(ALPHA), c_int(mode), ptr(gcls), ptr(greg), c_int(0), c_int(0), c_int(0), stream_of(cls))
     return gcls, greg
 
 

@@ -1,0 +1,73 @@
+"""CPU-side host logic: API surface, state_dict compatibility with the reference (keys + OIHW
+shapes recorded in the golden files), symbol export of the C ABI, loud failure without a GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from objectdetection.pytorch_amd import _lib
+    names = _lib.declared_symbols()
+    assert 'mi355_conv_gather' in names and 'mi355_focal_loss_fwd' in names and len(names) >= 25
+    lib = _lib.lib()
+    for n in names:
+        assert hasattr(lib, n), 'libmi355det.so does not export %s' % n
+    assert lib.mi355_version() >= 1
+
+
+@pytest.mark.parametrize('tag,depth', [('r18_256', 18), ('r50_128x160', 50)])
+def test_state_dict_matches_reference(golden_dir, tag, depth):
+    from objectdetection.pytorch_amd.architectures import retinanet
+    g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
+    nc = int(g['num_classes'])
+    model = retinanet.retinanet(depth, num_classes=nc)
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g['state_keys']]
+    assert [','.join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g['state_shapes']]
+    # reference init values (retinanet.py:240-246)
+    assert float(sd['classificationModel.output.weight'].abs().max()) == 0.0
+    np.testing.assert_allclose(sd['classificationModel.output.bias'].numpy(), -np.log(99.0), rtol=1e-6)
+    assert all(not m.training for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    # a reference-layout (contiguous OIHW) checkpoint loads, masters stay KRSC in memory
+    model.load_state_dict({k: v.contiguous() for k, v in sd.items()})
+    assert model.layer1[0].conv1.weight.stride(1) == 1
+
+
+def test_factories_and_attrs():
+    from objectdetection.pytorch_amd.architectures import retinanet, anchors, losses, utils
+    m = retinanet.build_retinanet('retinanet-res18', num_classes=3)
+    assert isinstance(m.anchors, anchors.Anchors) and isinstance(m.focalLoss, losses.FocalLoss)
+    assert isinstance(m.regressBoxes, utils.BBoxTransform) and isinstance(m.clipBoxes, utils.ClipBoxes)
+    assert m.anchors.strides == [8, 16, 32, 64, 128] and m.anchors.sizes == [32, 64, 128, 256, 512]
+    assert sum(p.numel() for p in retinanet.retinanet18(80).parameters()) == 21410100
+    with pytest.raises(RuntimeError):
+        retinanet.retinanet50(80, pretrained=True)           # must never fetch
+    m.train()
+    m.freeze_bn()
+    assert not m.bn1.training and m.training
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly off-GPU (never route through the oracle)."""
+    from objectdetection.pytorch_amd.architectures import retinanet, losses, utils
+    m = retinanet.retinanet18(4)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 64, 64), torch.zeros(1, 1, 5))
+    with pytest.raises(RuntimeError):
+        m.layer1[0](torch.zeros(1, 64, 8, 8))
+    with pytest.raises(RuntimeError):
+        losses.FocalLoss()(torch.rand(1, 9, 2), torch.rand(1, 9, 4), torch.rand(1, 9, 4), -torch.ones(1, 1, 5))
+    with pytest.raises(RuntimeError):
+        utils.BBoxTransform()(torch.rand(1, 9, 4), torch.rand(1, 9, 4))
+    import objectdetection.pytorch_amd as pkg
+    src = open(os.path.join(os.path.dirname(pkg.__file__), 'engine.py')).read()
+    assert 'oracle' not in src
+
+
+def test_oracle_state_shapes_helper():
+    s = ref_cpu.retinanet_state_shapes(50, 80)
+    assert len(s) == 354
