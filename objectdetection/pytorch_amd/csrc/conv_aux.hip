@@ -94,32 +94,44 @@ extern "C" int mi355_prep_weight(const float* w, int64_t sk, int64_t sc, int64_t
 }
 
 // ----------------------------------------------------------------------- column sums
-__global__ void colsum_kernel(const unsigned short* __restrict__ g, long long M, int K, int rsplit,
-                              float* __restrict__ out) {
+// out[k] += sum_m g[m][k].  One block streams `rows_per_block` consecutive rows with 16-B loads
+// (thread = (row phase, 8-column chunk)), reduces the row phases through LDS and issues ONE
+// atomic per column per block.
+__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ g, long long M,
+                                                     int K, int rows_per_block, float* __restrict__ out) {
+    __shared__ float s_acc[2048 + 8];
     const int k8n = K >> 3;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)k8n * rsplit) return;
-    const int k8 = (int)(t % k8n);
-    const int rs = (int)(t / k8n);
+    const int rpb = 256 / k8n;                       // row phases handled concurrently
+    const int tid = threadIdx.x;
+    const int rsub = tid / k8n, k8 = tid - rsub * k8n;
+    const long long row0 = (long long)blockIdx.x * rows_per_block;
+    const long long row1 = row0 + rows_per_block < M ? row0 + rows_per_block : M;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long long m = rs; m < M; m += rsplit) {
-        const s8v v = *reinterpret_cast<const s8v*>(g + m * K + k8 * 8);
+    if (rsub < rpb) {
+        for (long long m = row0 + rsub; m < row1; m += rpb) {
+            const s8v v = *reinterpret_cast<const s8v*>(g + m * K + k8 * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += bf16_to_f32((unsigned short)v[e]);
+            for (int e = 0; e < 8; ++e) acc[e] += bf16_to_f32((unsigned short)v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_acc[rsub * K + k8 * 8 + e] = acc[e];
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + k8 * 8 + e, acc[e]);
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+        float t = 0.0f;
+        for (int r = 0; r < rpb; ++r) t += s_acc[r * K + k];
+        atomicAdd(out + k, t);
+    }
 }
 
 extern "C" int mi355_colsum_bf16(const void* g, int64_t M, int K, float* out, void* stream) {
-    MI355_REQUIRE(g && out && M > 0 && K > 0 && K % 8 == 0, "colsum: K must be a multiple of 8");
-    const int k8n = K / 8;
-    long long rsplit = 65536 / k8n;
-    if (rsplit < 1) rsplit = 1;
-    if (rsplit > M) rsplit = M;
-    const long long threads = (long long)k8n * rsplit;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(threads, 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const unsigned short*)g, (long long)M, K, (int)rsplit, out);
+    MI355_REQUIRE(g && out && M > 0 && K > 0 && K % 8 == 0 && K <= 2048,
+                  "colsum: K must be a multiple of 8, <= 2048");
+    long long rows = (M + 1023) / 1024;              // ~1024 blocks
+    if (rows < 64) rows = 64;
+    const long long blocks = (M + rows - 1) / rows;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)g, (long long)M, K, (int)rows, out);
     return check_launch("colsum_kernel");
 }
 

@@ -37,4 +37,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 
 constexpr unsigned OOB_OFFSET = 0x80000000u;
 
+// Division by a launch constant: floor(x / d) = umulhi(x, mul) >> shr for x < 2^31.
+struct FastDiv {
+    unsigned mul, shr, d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) { f.mul = 0; f.shr = 0; f.d = 1; return f; }
+    unsigned l = 0;
+    while ((1u << l) < d) ++l;
+    const unsigned p = 31 + l;
+    f.mul = (unsigned)(((1ull << p) + d - 1) / d);
+    f.shr = p - 32;
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned x, const FastDiv f) {
+    return f.d == 1 ? x : (__umulhi(x, f.mul) >> f.shr);
+}
+
 }  // namespace mi355

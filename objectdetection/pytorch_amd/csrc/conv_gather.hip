@@ -25,8 +25,9 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;          // 32 KiB
-constexpr int EPI_LD = BN + 4;                           // fp32 row stride of the epilogue image
-constexpr int LDS_BYTES = (2 * STAGE_BYTES > BM * EPI_LD * 4) ? 2 * STAGE_BYTES : BM * EPI_LD * 4;
+constexpr int EPI_LD = BN + 4;                           // fp32 staging row stride (floats): 64-row halves
+constexpr int EPI16_LD = BN + 4;                         // bf16 staging row stride (elements), 264 B
+constexpr int EPI_BYTES = 64 * EPI_LD * 4;               // 33792 B = 128 * EPI16_LD * 2 as well
 
 struct ProbDev {
     const unsigned short* in;
@@ -44,6 +45,7 @@ struct ProbDev {
     int tile_begin;
     int M;
     int in_bytes;
+    FastDiv dPQ, dQ;
 };
 
 struct LaunchDev {
@@ -59,7 +61,10 @@ __device__ __forceinline__ float activate(float v, int act) {
     return v;
 }
 
-template <bool FLAT>
+// STAGES = 2: double-buffered k-loop, 64 KiB LDS, 2 blocks/CU (MFMA-bound shapes).
+// STAGES = 1: one stage, 32 KiB LDS, 4 blocks/CU: short reductions (<= 2 k-steps) are HBM-bound
+//             and live on bytes in flight, i.e. on resident blocks, not on intra-block overlap.
+template <bool FLAT, int STAGES>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDev L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ long long s_outoff[BM];
@@ -70,10 +75,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
     const int m_tile = tile / L.n_tiles, n_tile = tile - m_tile * L.n_tiles;
 
     // ---- select the problem of this tile (scalar selects over the by-value descriptors)
-    ProbDev P = L.p[0];
+    int pi = 0;
 #pragma unroll
     for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
-        if (i < L.nprob && m_tile >= L.p[i].tile_begin) P = L.p[i];
+        if (i < L.nprob && m_tile >= L.p[i].tile_begin) pi = i;
+    const ProbDev P = L.p[pi];                           // one block copy out of the kernarg segment
     const int m0 = (m_tile - P.tile_begin) * BM;
     const int n0 = n_tile * BN;
     const int PQ = P.P * P.Q;
@@ -83,7 +89,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
         const int m = m0 + tid;
         long long oo = -1, ao = -1;
         if (m < P.M) {
-            const int n = m / PQ, rem = m - n * PQ, p = rem / P.Q, q = rem - p * P.Q;
+            const int n = (int)fdiv((unsigned)m, P.dPQ), rem = m - n * PQ;
+            const int p = (int)fdiv((unsigned)rem, P.dQ), q = rem - p * P.Q;
             oo = n * P.out_sN + (long long)(p * P.out_mh + P.out_oh) * P.out_sH +
                  (long long)(q * P.out_mw + P.out_ow) * P.out_sW;
             ao = n * P.add_sN + (long long)(p >> P.add_shift) * P.add_sH +
@@ -104,15 +111,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
     for (int i = 0; i < 4; ++i) {
         const int row = (tid >> 3) + 32 * i;
         const int m = m0 + row;
-        if (m < P.M) {
-            const int n = m / PQ, rem = m - n * PQ, p = rem / P.Q, q = rem - p * P.Q;
-            a_ih0[i] = p * P.sh + P.dh0;
+        {
+            const int mc = min(m, P.M - 1);
+            const int n = (int)fdiv((unsigned)mc, P.dPQ), rem = mc - n * PQ;
+            const int p = (int)fdiv((unsigned)rem, P.dQ), q = rem - p * P.Q;
+            a_ih0[i] = m < P.M ? p * P.sh + P.dh0 : -0x40000000;   // tail rows: never valid
             a_iw0[i] = q * P.sw + P.dw0;
-            a_base[i] = n * (int)P.in_sN + (a_ih0[i] * P.W + a_iw0[i]) * P.C;
-        } else {
-            a_ih0[i] = -0x40000000;                   // never valid
-            a_iw0[i] = 0;
-            a_base[i] = 0;
+            a_base[i] = n * (int)P.in_sN + ((p * P.sh + P.dh0) * P.W + a_iw0[i]) * P.C;
         }
         const int nn = n0 + row;
         b_rowoff[i] = nn < L.K ? (unsigned)(nn * wrow) * 2u : OOB_OFFSET;
@@ -162,14 +167,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
         }
     };
 
-    f4v acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
-
     const int wm = wv >> 1, wn = wv & 1;
     const int fr = lane & 15, fq = lane >> 4;
+    f4v acc[4][4];
+    // epilogue geometry
+    const int col = (tid & 15) * 8;
+    const int k0 = n0 + col;
+    const int nvalid = min(8, L.K - k0);
     // ds_read_b128 byte offsets of this lane's fragments inside a stage (row r, chunk c):
     //   r*128 + ((c ^ (r & 7)) << 4); r & 7 == fr & 7 for every 16-row tile.
     const int a_rd = (wm * 64 + fr) * 128;
@@ -177,11 +181,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
     const int sw0 = ((fq) ^ (fr & 7)) << 4;           // k-sub 0: chunk fq
     const int sw1 = ((4 + fq) ^ (fr & 7)) << 4;       // k-sub 1: chunk 4 + fq
 
-    if (ksteps > 0) issue(0, 0);
-    __syncthreads();
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < ksteps) issue(ks + 1, buf ^ 1);
+    auto compute = [&](int buf) {
         const unsigned char* st = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -196,87 +196,176 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
-    }
-
-    // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> coalesced rows
-    float* epi = reinterpret_cast<float*>(smem);
+    };
+    if (ksteps > 0) issue(0, 0);
+    // (bias loads are issued behind the first stage's DMA so that both latencies overlap)
+    // Accumulators hold the TRANSPOSED tile: acc[i][j][r] = out[pixel i*16+fr][channel j*16+fq*4+r]
+    // (weights are the MFMA A operand), so a lane owns 4 consecutive channels of one pixel and
+    // the epilogue stages with 8/16-B LDS writes.  The bias is the accumulator's initial value.
+    {
+        f4v b4[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) b4[j] = (f4v){0.f, 0.f, 0.f, 0.f};
+        if (L.bias) {                                  // uniform branch; 4 loads in flight together
+            if ((L.K & 3) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    b4[j] = *reinterpret_cast<const f4v*>(L.bias + min(n0 + wn * 64 + j * 16 + fq * 4, L.K - 4));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        b4[j][r] = L.bias[min(n0 + wn * 64 + j * 16 + fq * 4 + r, L.K - 1)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    b4[j][r] = (n0 + wn * 64 + j * 16 + fq * 4 + r) < L.K ? b4[j][r] : 0.0f;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                epi[(wm * 64 + i * 16 + fq * 4 + r) * EPI_LD + wn * 64 + j * 16 + fr] = acc[i][j][r];
+            for (int i = 0; i < 4; ++i) acc[i][j] = b4[j];
+    }
     __syncthreads();
+    if (STAGES == 2) {
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int buf = ks & 1;
+            if (ks + 1 < ksteps) issue(ks + 1, buf ^ 1);
+            compute(buf);
+            __syncthreads();
+        }
+    } else {
+        for (int ks = 0; ks < ksteps; ++ks) {
+            compute(0);
+            __syncthreads();
+            if (ks + 1 < ksteps) {
+                issue(ks + 1, 0);
+                __syncthreads();
+            }
+        }
+    }
 
-    const int cchunk = tid & 15;
-    const int col = cchunk * 8;
-    const int k0 = n0 + col;
-    if (k0 < L.K) {
-        const int nvalid = min(8, L.K - k0);
-        float bias[8];
+    // ---- epilogue
+    const bool full = nvalid == 8;
+    const bool mask_first = (L.flags & 1) != 0;
+    const bool fast = !L.out_f32 && !P.addend && (L.K & 7) == 0;
+    if (fast) {
+        // FAST: activation in registers, bf16 staging of the whole tile (one barrier), the read
+        // side is a 16-B copy (+ the ReLU-backward mask as a bit select).
+        unsigned short* st16 = reinterpret_cast<unsigned short*>(smem);
+        long long oo[8];
+        s8v mk[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bias[e] = (L.bias && e < nvalid) ? L.bias[k0 + e] : 0.0f;
+        for (int pass = 0; pass < 8; ++pass) {       // mask reads first: latency hides under staging
+            const int row = pass * 16 + (tid >> 4);
+            oo[pass] = k0 < L.K ? s_outoff[row] : -1;
+            mk[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+            if (P.mask && oo[pass] >= 0) mk[pass] = *reinterpret_cast<const s8v*>(P.mask + oo[pass] + k0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s4v pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_rn(activate(acc[i][j][r], L.act));
+                *reinterpret_cast<s4v*>(st16 + (wm * 64 + i * 16 + fr) * EPI16_LD + wn * 64 + j * 16 + fq * 4) = pk;
+            }
+        __syncthreads();
 #pragma unroll
         for (int pass = 0; pass < 8; ++pass) {
+            if (oo[pass] < 0) continue;
             const int row = pass * 16 + (tid >> 4);
-            const long long oo = s_outoff[row];
-            if (oo < 0) continue;
-            const f4v v0 = *reinterpret_cast<const f4v*>(epi + row * EPI_LD + col);
-            const f4v v1 = *reinterpret_cast<const f4v*>(epi + row * EPI_LD + col + 4);
+            const s4v lo = *reinterpret_cast<const s4v*>(st16 + row * EPI16_LD + col);
+            const s4v hi = *reinterpret_cast<const s4v*>(st16 + row * EPI16_LD + col + 4);
+            s8v o = (s8v){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (P.mask) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)       // bf16 > 0  <=>  sign clear and not +-0
+                    o[e] = ((unsigned short)mk[pass][e] & 0x8000u) || !((unsigned short)mk[pass][e] & 0x7fffu) ? (short)0 : o[e];
+            }
+            *reinterpret_cast<s8v*>(reinterpret_cast<unsigned short*>(P.out) + oo[pass] + k0) = o;
+        }
+        return;
+    }
+    // GENERAL: fp32 staging in two 64-row halves (addend / fp32 output / ragged channel tails)
+    float* epi = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        long long oo[4];
+        s8v mk[4], ad[4];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = half * 64 + pass * 16 + (tid >> 4);
+            oo[pass] = k0 < L.K ? s_outoff[row] : -1;
+            mk[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+            ad[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+            if (oo[pass] >= 0 && full) {
+                if (P.mask) mk[pass] = *reinterpret_cast<const s8v*>(P.mask + oo[pass] + k0);
+                if (P.addend) ad[pass] = *reinterpret_cast<const s8v*>(P.addend + s_addoff[row] + k0);
+            }
+        }
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f4v*>(epi + (i * 16 + fr) * EPI_LD + wn * 64 + j * 16 + fq * 4) = acc[i][j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            if (oo[pass] < 0) continue;
+            const int hrow = pass * 16 + (tid >> 4);
+            const f4v v0 = *reinterpret_cast<const f4v*>(epi + hrow * EPI_LD + col);
+            const f4v v1 = *reinterpret_cast<const f4v*>(epi + hrow * EPI_LD + col + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (full) {
+                if (P.mask && mask_first) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bias[e];
-            const bool mask_first = (L.flags & 1) != 0;
-            if (P.mask && mask_first) {
-                const unsigned short* mp = P.mask + oo + k0;
-                for (int e = 0; e < nvalid; ++e) v[e] = bf16_to_f32(mp[e]) > 0.0f ? v[e] : 0.0f;
-            }
-            if (P.addend) {
-                const unsigned short* ap = P.addend + s_addoff[row] + k0;
-                if (nvalid == 8) {
-                    const s8v a = *reinterpret_cast<const s8v*>(ap);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((unsigned short)a[e]);
-                } else {
-                    for (int e = 0; e < nvalid; ++e) v[e] += bf16_to_f32(ap[e]);
+                    for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((unsigned short)mk[pass][e]) > 0.0f ? v[e] : 0.0f;
                 }
-            }
+                if (P.addend) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = activate(v[e], L.act);
-            if (P.mask && !mask_first) {
-                const unsigned short* mp = P.mask + oo + k0;
-                if (nvalid == 8) {
-                    const s8v a = *reinterpret_cast<const s8v*>(mp);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((unsigned short)a[e]) > 0.0f ? v[e] : 0.0f;
-                } else {
-                    for (int e = 0; e < nvalid; ++e) v[e] = bf16_to_f32(mp[e]) > 0.0f ? v[e] : 0.0f;
+                    for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((unsigned short)ad[pass][e]);
                 }
-            }
-            if (L.out_f32) {
-                float* op = reinterpret_cast<float*>(P.out) + oo + k0;
-                if (nvalid == 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = activate(v[e], L.act);
+                if (P.mask && !mask_first) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((unsigned short)mk[pass][e]) > 0.0f ? v[e] : 0.0f;
+                }
+                if (L.out_f32) {
+                    float* op = reinterpret_cast<float*>(P.out) + oo[pass] + k0;
                     *reinterpret_cast<f4v*>(op) = (f4v){v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f4v*>(op + 4) = (f4v){v[4], v[5], v[6], v[7]};
                 } else {
-                    for (int e = 0; e < nvalid; ++e) op[e] = v[e];
-                }
-            } else {
-                unsigned short* op = reinterpret_cast<unsigned short*>(P.out) + oo + k0;
-                if (nvalid == 8) {
                     s8v o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(v[e]);
-                    *reinterpret_cast<s8v*>(op) = o;
-                } else {
-                    for (int e = 0; e < nvalid; ++e) op[e] = f32_to_bf16_rn(v[e]);
+                    *reinterpret_cast<s8v*>(reinterpret_cast<unsigned short*>(P.out) + oo[pass] + k0) = o;
+                }
+            } else {                               // ragged channel tail (K % 8 != 0): scalar path
+                const int row = half * 64 + hrow;
+                const unsigned short* mp = P.mask ? P.mask + oo[pass] + k0 : nullptr;
+                const unsigned short* ap = P.addend ? P.addend + s_addoff[row] + k0 : nullptr;
+                for (int e = 0; e < nvalid; ++e) {
+                    float x = v[e];
+                    if (mp && mask_first) x = bf16_to_f32(mp[e]) > 0.0f ? x : 0.0f;
+                    if (ap) x += bf16_to_f32(ap[e]);
+                    x = activate(x, L.act);
+                    if (mp && !mask_first) x = bf16_to_f32(mp[e]) > 0.0f ? x : 0.0f;
+                    if (L.out_f32) (reinterpret_cast<float*>(P.out) + oo[pass] + k0)[e] = x;
+                    else (reinterpret_cast<unsigned short*>(P.out) + oo[pass] + k0)[e] = f32_to_bf16_rn(x);
                 }
             }
         }
+        if (half == 0) __syncthreads();
     }
 }
 
@@ -314,6 +403,8 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
         d.add_sN = s.add_sN; d.add_sH = s.add_sH; d.add_sW = s.add_sW; d.add_shift = s.add_shift;
         d.in_sN = in_sN;
         d.M = s.N * s.P * s.Q;
+        d.dPQ = make_fastdiv((unsigned)(s.P * s.Q));
+        d.dQ = make_fastdiv((unsigned)s.Q);
         d.in_bytes = (int)in_bytes;
         d.tile_begin = tiles;
         tiles += (int)cdiv(d.M, BM);
@@ -329,17 +420,28 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
     L.w_bytes = (int)w_bytes;
     const long long grid = (long long)tiles * L.n_tiles;
     MI355_REQUIRE(grid > 0 && grid < 0x7fffffffLL, "conv_gather: grid");
+    // k-steps of the longest problem decide the pipeline depth
+    int max_ksteps = 0;
+    for (int i = 0; i < in.nprob; ++i) {
+        const int taps = in.prob[i].TR * in.prob[i].TS;
+        const int ks = flat ? (taps * (C / 8) + 7) / 8 : taps * (C / BK);
+        if (ks > max_ksteps) max_ksteps = ks;
+    }
+    const bool single = max_ksteps <= 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
         attr_set = true;
     }
-    if (flat)
-        hipLaunchKernelGGL(conv_gather_kernel<true>, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES,
-                           (hipStream_t)stream, L);
-    else
-        hipLaunchKernelGGL(conv_gather_kernel<false>, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES,
-                           (hipStream_t)stream, L);
+    const dim3 g((unsigned)grid), b(NTHREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (single) {
+        if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1>), g, b, EPI_BYTES, st, L);
+        else      hipLaunchKernelGGL((conv_gather_kernel<false, 1>), g, b, EPI_BYTES, st, L);
+    } else {
+        if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 2>), g, b, 2 * STAGE_BYTES, st, L);
+        else      hipLaunchKernelGGL((conv_gather_kernel<false, 2>), g, b, 2 * STAGE_BYTES, st, L);
+    }
     return check_launch("conv_gather_kernel");
 }

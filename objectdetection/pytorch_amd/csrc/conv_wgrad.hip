@@ -25,24 +25,6 @@ constexpr int STAGE_BYTES = (TK + TC) * RM * 2;           // 32 KiB
 constexpr int EPI_LD = TC + 4;
 constexpr int LDS_BYTES = (2 * STAGE_BYTES > TK * EPI_LD * 4) ? 2 * STAGE_BYTES : TK * EPI_LD * 4;
 
-struct FastDiv {
-    unsigned mul, shr, d;
-};
-static FastDiv make_fastdiv(unsigned d) {
-    FastDiv f;
-    f.d = d;
-    if (d == 1) { f.mul = 0; f.shr = 0; return f; }
-    unsigned l = 0;
-    while ((1u << l) < d) ++l;
-    const unsigned p = 31 + l;
-    f.mul = (unsigned)(((1ull << p) + d - 1) / d);
-    f.shr = p - 32;
-    return f;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned x, const FastDiv f) {   // x < 2^31
-    return f.d == 1 ? x : (__umulhi(x, f.mul) >> f.shr);
-}
-
 struct WProb {
     const unsigned short* in;
     const unsigned short* dy;
@@ -61,6 +43,7 @@ struct WLaunch {
     int nprob, K, T, k_tiles, c_tiles, ntaps, split_rows;
 };
 
+template <bool FLAT>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -79,9 +62,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
         if (i < L.nprob && chunk >= L.p[i].chunk_begin) P = L.p[i];
     const int m_begin = (chunk - P.chunk_begin) * L.split_rows;
     const int m_end = min(P.M, m_begin + L.split_rows);
-    const int ti = tap / P.TS, tj = tap - ti * P.TS;
-    const int dh = P.dh0 + ti * P.dhs, dw = P.dw0 + tj * P.dws;
-    const int wtap = (P.r0 + ti * P.rs) * P.S + (P.s0 + tj * P.ss);
     const int k0 = k_tile * TK, c0 = c_tile * TC;
 
     const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(P.in, (unsigned)P.in_bytes);
@@ -93,8 +73,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
     const int fsw = ((srow & 3) | (((srow >> 3) & 1) << 2)) << 1;
     const int lchunk = slot ^ fsw;
     const int ky = k0 + lchunk * 8;                    // dy channel of this thread's chunk
-    const int cx = c0 + lchunk * 8;                    // input channel of this thread's chunk
-    const bool ky_ok = ky + 8 <= L.K, cx_ok = cx + 8 <= P.C;
+    const bool ky_ok = ky + 8 <= L.K;
+    // input-side column chunk: one tap per block (tap-uniform) or, FLAT (C < 128), the tile's
+    // 128 columns run over (tap, channel) so that small-C layers fill the MFMA tile
+    int cx, dh, dw;
+    bool cx_ok;
+    if (FLAT) {
+        const int cpt = P.C >> 3;
+        const int J = c_tile * 16 + lchunk;
+        const int tp = J / cpt;
+        cx = (J - tp * cpt) * 8;
+        const int ti = tp / P.TS, tj = tp - ti * P.TS;
+        dh = P.dh0 + ti * P.dhs;
+        dw = P.dw0 + tj * P.dws;
+        cx_ok = tp < P.TR * P.TS;
+    } else {
+        const int ti = tap / P.TS, tj = tap - ti * P.TS;
+        dh = P.dh0 + ti * P.dhs;
+        dw = P.dw0 + tj * P.dws;
+        cx = c0 + lchunk * 8;
+        cx_ok = cx + 8 <= P.C;
+    }
 
     auto issue = [&](int step, int buf) {
         unsigned char* sy = smem + buf * STAGE_BYTES;
@@ -179,15 +178,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
                 epi[(wk * 64 + i * 16 + fq * 4 + r) * EPI_LD + wc * 64 + j * 16 + fr] = acc[i][j][r];
     __syncthreads();
     const long long wrow = (long long)L.T * P.C;
+    long long coff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                      // weight-row offset of this lane's columns
+        const int c = h * 64 + lane;
+        coff[h] = -1;
+        if (FLAT) {
+            const int J8 = c_tile * TC + c;
+            const int tp = J8 / P.C, cc = J8 - tp * P.C;
+            const int ti = tp / P.TS, tj = tp - ti * P.TS;
+            if (tp < P.TR * P.TS) coff[h] = (long long)((P.r0 + ti * P.rs) * P.S + (P.s0 + tj * P.ss)) * P.C + cc;
+        } else {
+            const int ti = tap / P.TS, tj = tap - ti * P.TS;
+            if (c0 + c < P.C) coff[h] = (long long)((P.r0 + ti * P.rs) * P.S + (P.s0 + tj * P.ss)) * P.C + c0 + c;
+        }
+    }
     for (int rr = wv; rr < TK; rr += 4) {
         const int k = k0 + rr;
         if (k >= L.K) break;
-        float* dst = L.dw + k * wrow + (long long)wtap * P.C + c0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = h * 64 + lane;
-            if (c0 + c < P.C) atomicAdd(dst + c, epi[rr * EPI_LD + c]);
-        }
+        for (int h = 0; h < 2; ++h)
+            if (coff[h] >= 0) atomicAdd(L.dw + k * wrow + coff[h], epi[rr * EPI_LD + h * 64 + lane]);
     }
 }
 
@@ -230,16 +241,23 @@ extern "C" int mi355_conv_wgrad(const Mi355ConvLaunch* launch, float* dw, int sp
     if (ntaps == 0) return MI355_OK;
     L.dw = dw;
     L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.ntaps = ntaps; L.split_rows = split_rows;
+    const bool flat = C < TC;
     L.k_tiles = (int)cdiv(in.K, TK);
-    L.c_tiles = (int)cdiv(C, TC);
-    const long long grid = (long long)chunks * ntaps * L.k_tiles * L.c_tiles;
+    L.c_tiles = flat ? (int)cdiv((long long)ntaps * C, TC) : (int)cdiv(C, TC);
+    if (flat) L.ntaps = 1;
+    const long long grid = (long long)chunks * L.ntaps * L.k_tiles * L.c_tiles;
     MI355_REQUIRE(grid > 0 && grid < 0x7fffffffLL, "conv_wgrad: grid");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES,
-                       (hipStream_t)stream, L);
+    if (flat)
+        hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES,
+                           (hipStream_t)stream, L);
+    else
+        hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES,
+                           (hipStream_t)stream, L);
     return check_launch("conv_wgrad_kernel");
 }

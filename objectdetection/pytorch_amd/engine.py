@@ -224,8 +224,7 @@ class RetinaPlan(object):
         for j, pr in enumerate(problems):
             L.prob[j] = pr
         L.nprob, L.K, L.T = len(problems), spec.Kpad, spec.T
-        tiles = spec.T * (-(-spec.Kpad // 128)) * (-(-spec.Cpad // 128))
-        split = pick_split_rows(rows, tiles)
+        split = pick_split_rows(rows, ops_conv.wgrad_tiles(spec.Kpad, spec.Cpad, spec.T))
         self._step(self.bwd_steps, 'mi355_conv_wgrad', ctypes.byref(L), ptr(spec.G), c_int(split))
         self.keep.append(L)
         spec._wgrad_launch = L

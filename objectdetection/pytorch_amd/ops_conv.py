@@ -112,11 +112,18 @@ def launch_wgrad(problems, K, T, dw, split_rows, stream_tensor):
     call('mi355_conv_wgrad', ctypes.byref(L), ptr(dw), c_int(split_rows), stream_of(stream_tensor))
 
 
-def pick_split_rows(total_rows, tiles_per_chunk, target_blocks=1024):
-    """Rows of the pixel reduction per block so that the launch has ~target_blocks blocks."""
+def wgrad_tiles(kpad, cpad, taps):
+    """Output tiles of one pixel chunk of the wgrad launch (mirrors conv_wgrad.hip)."""
+    kt = -(-kpad // 128)
+    return kt * (-(-taps * cpad // 128)) if cpad < 128 else kt * taps * (-(-cpad // 128))
+
+
+def pick_split_rows(total_rows, tiles_per_chunk, target_blocks=512, min_rows=512):
+    """Rows of the pixel reduction per block: ~2 blocks per CU, but never so few rows that the
+    fp32-atomic epilogue (64 KiB per block) outweighs the MFMA work."""
     chunks = max(1, target_blocks // max(1, tiles_per_chunk))
     rows = -(-total_rows // chunks)
-    rows = max(256, -(-rows // 64) * 64)
+    rows = max(min_rows, -(-rows // 64) * 64)
     return rows
 
 
@@ -152,7 +159,7 @@ def conv_wgrad(x, dy, R, S, stride, pad, split_rows=None, out=None):
     pr = fwd_problem(x, dy.data_ptr(), R, S, stride, pad, K=Kp)
     M = N * pr.P * pr.Q
     if split_rows is None:
-        split_rows = pick_split_rows(M, T * (-(-Kp // 128)) * (-(-C // 128)))
+        split_rows = pick_split_rows(M, wgrad_tiles(Kp, C, T))
     launch_wgrad([pr], Kp, T, out, split_rows, x)
     return out
 
