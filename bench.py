@@ -98,7 +98,7 @@ def conv_flops(plan):
 def time_conv_kernels(plan, iters):
     """HIP-event time of ONLY the MFMA conv launches of one step (forward gather convs,
     backward gather convs = dgrad, wgrad), replayed back-to-back on the launch stream."""
-    names = ('mi355_conv_gather', 'mi355_conv_wgrad')
+    names = ('mi355_conv_gather', 'mi355_conv_wgrad', 'mi355_conv_wgrad_colsum')
     steps = [s for s in plan.fwd_steps + plan.bwd_steps if s[2] in names]
     st = torch.cuda.current_stream()
     plan.grad_arenas[0].zero_()

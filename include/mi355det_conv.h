@@ -65,6 +65,10 @@ int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream);
  * `out` holds the bf16 dy of that problem, [N][P*Q][K] with batch stride out_sN elements
  * (0 = dense). dw is fp32 [K][T][C]. */
 int mi355_conv_wgrad(const Mi355ConvLaunch* launch, float* dw, int split_rows, void* stream);
+/* Same, and additionally colsum[k] += sum_m dy[m][k] (fp32 [K], may be NULL): the bias / frozen-BN
+ * beta gradient, reduced from the dy fragments the kernel already holds (no extra HBM pass). */
+int mi355_conv_wgrad_colsum(const Mi355ConvLaunch* launch, float* dw, float* colsum, int split_rows,
+                            void* stream);
 
 /* ---- elementwise / layout helpers of the conv path --------------------------------------- */
 /* fp32 NCHW [N][C][H][W] -> bf16 NHWC [N][H][W][Cpad] (channels >= C zero). */

@@ -40,6 +40,7 @@ struct WProb {
 struct WLaunch {
     WProb p[MI355_CONV_MAX_PROBLEMS];
     float* dw;
+    float* colsum;
     int nprob, K, T, k_tiles, c_tiles, ntaps, split_rows;
 };
 
@@ -134,6 +135,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
     // logical 16-B chunk of (tile t of this wave, p4): 8*wk + 2t + (p4 >> 1) for dy, 8*wc + ... for x
     const int half8 = (p4 & 1) * 8;
 
+    // column sums of dy (bias / BN-beta gradient): only the blocks owning (tap 0, c-tile 0) and
+    // only their wc == 0 waves (the other column-waves hold the same dy fragments)
+    const bool do_colsum = L.colsum != nullptr && c_tile == 0 && tap == 0 && wc == 0;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
     const int nsteps = (m_end - m_begin + RM - 1) / RM;
     if (nsteps > 0) issue(0, 0);
     __syncthreads();
@@ -157,6 +162,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
                 af[t] = (s8v){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                 bf[t] = (s8v){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
             }
+            if (do_colsum) {                           // wave-uniform
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) csum[t] += bf16_to_f32((unsigned short)af[t][e]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -166,6 +177,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
         __syncthreads();
     }
 
+    if (do_colsum) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v = csum[t];
+            v += __shfl_xor(v, 16, 64);                // the 4 lane groups hold disjoint pixels
+            v += __shfl_xor(v, 32, 64);
+            const int k = k0 + wk * 64 + t * 16 + (lane & 15);
+            if (lane < 16 && k < L.K) atomicAdd(L.colsum + k, v);
+        }
+    }
     // ---- epilogue: LDS-staged, one 256-B contiguous atomic row segment per wave instruction
     float* epi = reinterpret_cast<float*>(smem);
     const int fr = lane & 15, fq = lane >> 4;
@@ -205,6 +226,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
 }  // namespace
 
 extern "C" int mi355_conv_wgrad(const Mi355ConvLaunch* launch, float* dw, int split_rows, void* stream) {
+    return mi355_conv_wgrad_colsum(launch, dw, nullptr, split_rows, stream);
+}
+
+extern "C" int mi355_conv_wgrad_colsum(const Mi355ConvLaunch* launch, float* dw, float* colsum,
+                                       int split_rows, void* stream) {
     MI355_REQUIRE(launch && dw, "conv_wgrad: null argument");
     const Mi355ConvLaunch& in = *launch;
     MI355_REQUIRE(in.nprob >= 1 && in.nprob <= MI355_CONV_MAX_PROBLEMS, "conv_wgrad: nprob");
@@ -240,6 +266,7 @@ extern "C" int mi355_conv_wgrad(const Mi355ConvLaunch* launch, float* dw, int sp
     }
     if (ntaps == 0) return MI355_OK;
     L.dw = dw;
+    L.colsum = colsum;
     L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.ntaps = ntaps; L.split_rows = split_rows;
     const bool flat = C < TC;
     L.k_tiles = (int)cdiv(in.K, TK);

@@ -219,13 +219,14 @@ class RetinaPlan(object):
         self._step(lst, 'mi355_conv_gather', ctypes.byref(L))
         self.keep.append(L)
 
-    def _wgrad(self, problems, spec, rows):
+    def _wgrad(self, problems, spec, rows, colsum=True):
         L = ConvLaunch()
         for j, pr in enumerate(problems):
             L.prob[j] = pr
         L.nprob, L.K, L.T = len(problems), spec.Kpad, spec.T
         split = pick_split_rows(rows, ops_conv.wgrad_tiles(spec.Kpad, spec.Cpad, spec.T))
-        self._step(self.bwd_steps, 'mi355_conv_wgrad', ctypes.byref(L), ptr(spec.G), c_int(split))
+        self._step(self.bwd_steps, 'mi355_conv_wgrad_colsum', ctypes.byref(L), ptr(spec.G),
+                   ptr(spec.colsum if colsum else None), c_int(split))
         self.keep.append(L)
         spec._wgrad_launch = L
 
@@ -244,9 +245,7 @@ class RetinaPlan(object):
         """wgrad (+ column sums) of `spec` and, optionally, its data gradient into `dx`."""
         N, H, W, C = x.shape
         pr = fwd_problem(x, dy.data_ptr(), spec.R, spec.S, spec.stride, spec.pad, K=spec.Kpad)
-        self._wgrad([pr], spec, N * pr.P * pr.Q)
-        self._step(self.bwd_steps, 'mi355_colsum_bf16', ptr(dy), c_i64(dy.numel() // dy.shape[-1]),
-                   c_int(dy.shape[-1]), ptr(spec.colsum))
+        self._wgrad([pr], spec, N * pr.P * pr.Q)          # + fused column sums (bias / beta grads)
         if not dgrad:
             return None
         if dx is None:
@@ -445,7 +444,6 @@ class RetinaPlan(object):
             dp.in_sN = self.ncells * kp
             dprobs.append(dp)
         self._wgrad(wprobs, out_spec, rows)
-        self._step(self.bwd_steps, 'mi355_colsum_bf16', ptr(gout), c_i64(rows), c_int(kp), ptr(out_spec.colsum))
         self._gather(self.bwd_steps, dprobs, out_spec.w_dgr, 256, 9)
         # tower convs 4..1
         for li in range(3, -1, -1):
@@ -453,7 +451,6 @@ class RetinaPlan(object):
             xs = acts[li - 1] if li > 0 else self.levels
             wprobs = [fwd_problem(x, gy.data_ptr(), 3, 3, 1, 1, K=256) for x, gy in zip(xs, gys)]
             self._wgrad(wprobs, spec, rows)
-            self._step(self.bwd_steps, 'mi355_colsum_bf16', ptr(gbuf), c_i64(rows), c_int(256), ptr(spec.colsum))
             if li > 0:
                 nbuf = self.new((rows, 256))
                 nys = self._level_views(nbuf)

@@ -104,12 +104,13 @@ def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE
         call('mi355_conv_gather', ctypes.byref(L), stream_of(stream_tensor))
 
 
-def launch_wgrad(problems, K, T, dw, split_rows, stream_tensor):
+def launch_wgrad(problems, K, T, dw, split_rows, stream_tensor, colsum=None):
     L = ConvLaunch()
     for j, pr in enumerate(problems):
         L.prob[j] = pr
     L.nprob, L.K, L.T = len(problems), K, T
-    call('mi355_conv_wgrad', ctypes.byref(L), ptr(dw), c_int(split_rows), stream_of(stream_tensor))
+    call('mi355_conv_wgrad_colsum', ctypes.byref(L), ptr(dw), ptr(colsum), c_int(split_rows),
+         stream_of(stream_tensor))
 
 
 def wgrad_tiles(kpad, cpad, taps):
@@ -148,7 +149,7 @@ def conv_dgrad(dy, w_dgr, H, W, Cin, R, S, stride, pad, addend=None, mask=None):
     return dx
 
 
-def conv_wgrad(x, dy, R, S, stride, pad, split_rows=None, out=None):
+def conv_wgrad(x, dy, R, S, stride, pad, split_rows=None, out=None, colsum=None):
     """-> G fp32 [Kpad][R*S][C] = sum_m dy[m][k] * x[m @ tap][c] (accumulates into `out`)."""
     require_gpu(x, dy)
     N, H, W, C = x.shape
@@ -160,7 +161,7 @@ def conv_wgrad(x, dy, R, S, stride, pad, split_rows=None, out=None):
     M = N * pr.P * pr.Q
     if split_rows is None:
         split_rows = pick_split_rows(M, wgrad_tiles(Kp, C, T))
-    launch_wgrad([pr], Kp, T, out, split_rows, x)
+    launch_wgrad([pr], Kp, T, out, split_rows, x, colsum=colsum)
     return out
 
 

@@ -152,9 +152,11 @@ def test_conv_wgrad(dev, case):
     dyh = torch.zeros((N, P, Q, kpad), dtype=torch.bfloat16, device=dev)
     dyh[..., :K] = dy.permute(0, 2, 3, 1).to(dev).to(torch.bfloat16)
     for split in (None, 64):
-        G = ops_conv.conv_wgrad(xh, dyh, R, R, stride, pad, split_rows=split)   # [Kpad][T][C]
+        cs = torch.zeros(kpad, device=dev)
+        G = ops_conv.conv_wgrad(xh, dyh, R, R, stride, pad, split_rows=split, colsum=cs)   # [Kpad][T][C]
         got = G[:K].reshape(K, R, R, C).permute(0, 3, 1, 2)
         _close(got, ref, 2e-3)
+        _close(cs[:K], dy.sum((0, 2, 3)), 1e-3)           # fused bias / BN-beta gradient
         if kpad > K:
             assert float(G[K:].abs().max()) == 0.0
 

@@ -19,7 +19,7 @@ st = torch.cuda.current_stream()
 rows = []
 for phase, steps in (('fwd', plan.fwd_steps), ('bwd', plan.bwd_steps)):
     for fn, args, name in steps:
-        if name not in ('mi355_conv_gather', 'mi355_conv_wgrad'):
+        if name not in ('mi355_conv_gather', 'mi355_conv_wgrad', 'mi355_conv_wgrad_colsum'):
             continue
         L = ctypes.cast(args[0], ctypes.POINTER(ops_conv.ConvLaunch)).contents if False else args[0]._obj
         flops = 0.0
@@ -42,7 +42,7 @@ for phase, steps in (('fwd', plan.fwd_steps), ('bwd', plan.bwd_steps)):
             fn(*args, s)
         e1.record(st); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 5 * 1e3
-        rows.append((phase, name[11:], L.nprob, p0.C, L.K, p0.TR, p0.TS, p0.sh, '+'.join(desc[:2]), flops, us))
+        rows.append((phase, name[11:17], L.nprob, p0.C, L.K, p0.TR, p0.TS, p0.sh, '+'.join(desc[:2]), flops, us))
 tot_f = sum(r[9] for r in rows); tot_t = sum(r[10] for r in rows)
 print('total %.1f GFLOP (padded channel counts) in %.2f ms = %.1f TFLOP/s' % (tot_f / 1e9, tot_t / 1e3, tot_f / tot_t / 1e6))
 agg = {}
