@@ -47,7 +47,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--graph', type=int, default=int(os.environ.get('MI355_GRAPH', '0')))
+    ap.add_argument('--torch-optim', action='store_true',
+                    help='autograd + torch clip/AdamW instead of the flat HIP optimizer')
     return ap.parse_args()
 
 
@@ -160,25 +161,29 @@ def main():
     # each rank owns its shard of the global batch (weak scaling: per-GPU batch fixed)
     img = torch.from_numpy(synth.synth_images(B, S, S, seed=100 + rank)).to(dev)
     ann = torch.from_numpy(synth.synth_annotations(B, S, S, 8, 16, num_classes, seed=200 + rank)).to(dev)
-    params = [p for p in model.parameters()]
-    try:
-        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=5e-4, fused=True)   # train.py:259-260
-    except Exception:
-        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=5e-4)
     loss_acc = torch.zeros(2, device=dev)
+    if args.torch_optim:
+        params = [p for p in model.parameters()]
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=5e-4)       # train.py:259-260
 
-    def step():
-        opt.zero_grad(set_to_none=True)                       # train.py:292
-        cl, rl = model(img, ann)                              # train.py:303
-        loss = cl.mean() + rl.mean()                          # train.py:312-314
-        loss.backward()                                       # train.py:319
-        plan = model._plans[next(iter(model._plans))]
-        arena = plan.grad_arenas[plan.last_arena]
-        if world > 1:
-            dist.all_reduce(arena, op=dist.ReduceOp.AVG)      # DP gradient exchange over xGMI
-        clip_grad_norm_flat_(arena, 0.1)                      # train.py:320
-        opt.step()                                            # train.py:321
-        loss_acc.add_(torch.cat([cl.detach(), rl.detach()]))
+        def step():
+            opt.zero_grad(set_to_none=True)                       # train.py:292
+            cl, rl = model(img, ann)                              # train.py:303
+            loss = cl.mean() + rl.mean()                          # train.py:312-314
+            loss.backward()                                       # train.py:319
+            plan = model._plans[next(iter(model._plans))]
+            arena = plan.grad_arenas[plan.last_arena]
+            if world > 1:
+                dist.all_reduce(arena, op=dist.ReduceOp.AVG)      # DP gradient exchange over xGMI
+            clip_grad_norm_flat_(arena, 0.1)                      # train.py:320
+            opt.step()                                            # train.py:321
+            loss_acc.add_(torch.cat([cl.detach(), rl.detach()]))
+    else:
+        from objectdetection.pytorch_amd.trainer import Trainer
+        trainer = Trainer(model, lr=1e-4, weight_decay=5e-4, clip_norm=0.1)   # train.py:259-260, 320
+
+        def step():
+            loss_acc.add_(trainer.step(img, ann))                 # fwd+loss+bwd+allreduce+clip+AdamW
 
     for _ in range(args.warmup):
         step()

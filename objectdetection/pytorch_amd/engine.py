@@ -145,7 +145,9 @@ class RetinaPlan(object):
             total += p.numel()
         self.grad_offsets = offs
         self.grad_numel = total
-        self.grad_arenas = [torch.zeros(total, dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.grad_numel_padded = (total + 3) // 4 * 4
+        self.grad_arenas = [torch.zeros(self.grad_numel_padded, dtype=torch.float32, device=self.dev)
+                            for _ in range(2)]
         self.active = 0
         shadow = sum(s.K * s.T * s.Cpad + (s.C * s.T * s.Kpad if s.need_dgrad else 0) for s in self.specs)
         self.shadow = self.new((shadow + 64,), torch.bfloat16, zero=True)

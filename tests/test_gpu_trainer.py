@@ -1,0 +1,112 @@
+"""GPU: the flat-arena Trainer (HIP clip + AdamW, no autograd) against the reference loop body
+(train.py:292-321) run with torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW on the same
+drop-in model through autograd."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dev, depth=18, nc=8):
+    from objectdetection.pytorch_amd.architectures import retinanet
+    model = retinanet.retinanet(depth, num_classes=nc)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=0.87)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    model.train()
+    model.freeze_bn()
+    return model
+
+
+def test_trainer_matches_torch_loop():
+    from objectdetection.pytorch_amd.trainer import Trainer
+    dev = torch.device('cuda', 0)
+    B, H, W, nc = 2, 128, 160, 8
+    img = torch.from_numpy(synth.synth_images(B, H, W, seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(B, H, W, 6, 8, nc, seed=2)).to(dev)
+    ref = _model(dev)
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=5e-4)
+    ref_losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        cl, rl = ref(img, ann)
+        (cl.mean() + rl.mean()).backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.1)
+        opt.step()
+        ref_losses.append([cl.item(), rl.item()])
+    mine = _model(dev)
+    p0 = {k: v.detach().clone() for k, v in mine.named_parameters()}
+    tr = Trainer(mine)
+    keys = list(mine.state_dict().keys())
+    got = [tr.step(img, ann).clone() for _ in range(3)]
+    assert tr.step_count == 3
+    assert list(mine.state_dict().keys()) == keys            # flattening keeps the state_dict
+    np.testing.assert_allclose(torch.stack(got).cpu().numpy(), np.array(ref_losses), rtol=1e-2)
+    for (k, a), (_, b) in zip(mine.named_parameters(), ref.named_parameters()):
+        da, db = (a - p0[k]).float(), (b - p0[k]).float()
+        # 3 Adam steps of lr 1e-4: |delta| <= ~3e-4 per element; wgrad atomics reorder sums
+        # Adam's first steps move every element by ~lr*sign(g): elements whose tiny gradient
+        # differs in the last bits (fp32 atomics reorder the wgrad sums) may differ by O(lr);
+        # the bulk must agree
+        # (exact optimizer arithmetic is pinned by test_flat_adamw_matches_torch below)
+        diff = (da - db).abs().detach()
+        assert float(diff.mean()) <= 0.15 * float(db.abs().mean()) + 1e-7, (k, float(diff.mean()))
+        assert float(db.abs().max()) > 0
+    # clip semantic: the gradient arena holds the clipped gradient (norm <= 0.1)
+    plan = mine._plans[next(iter(mine._plans))]
+    gn = float(torch.linalg.vector_norm(plan.grad_arenas[plan.last_arena]))
+    assert gn <= 0.1 * 1.001
+
+
+def test_trainer_skips_zero_loss_step():
+    """train.py:316-317: `if bool(loss == 0): continue` (all images without annotations)."""
+    from objectdetection.pytorch_amd.trainer import Trainer
+    dev = torch.device('cuda', 0)
+    mine = _model(dev)
+    tr = Trainer(mine)
+    img = torch.from_numpy(synth.synth_images(2, 64, 64, seed=1)).to(dev)
+    ann = -torch.ones(2, 1, 5, device=dev)
+    before = tr.flat.clone()
+    losses = tr.step(img, ann)
+    assert float(losses.abs().sum()) == 0.0
+    assert torch.equal(tr.flat, before) and tr.step_count == 0
+
+
+def test_flat_adamw_matches_torch():
+    """clip_grad_norm_(0.1) + AdamW(lr 1e-4, wd 5e-4) on identical gradients: the three HIP
+    launches against torch's own implementation, 4 steps (bias correction included)."""
+    import ctypes
+    from objectdetection.pytorch_amd import _lib
+    from objectdetection.pytorch_amd._lib import c_f32, c_i64, c_int, c_vp, ptr
+    dev = torch.device('cuda', 0)
+    n = 1000004
+    g = torch.Generator(device='cpu').manual_seed(3)
+    p0 = torch.randn(n, generator=g).to(dev)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-4, weight_decay=5e-4)
+    flat, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    state = torch.zeros(4, dtype=torch.int32, device=dev)
+    partials = torch.zeros(1024, device=dev)
+    st = c_vp(torch.cuda.current_stream().cuda_stream)
+    for it in range(4):
+        grad = (torch.randn(n, generator=g) * (0.001 if it % 2 else 10.0)).to(dev)   # clipped / not
+        ref.grad = grad.clone()
+        total = torch.nn.utils.clip_grad_norm_([ref], 0.1)
+        opt.step()
+        mine = grad.clone()
+        _lib.call('mi355_grad_sumsq', ptr(mine), c_i64(n), ptr(partials), st)
+        _lib.call('mi355_adamw_prepare', ptr(partials), c_vp(0), c_f32(0.1), ptr(state), st)
+        _lib.call('mi355_adamw_flat', ptr(flat), ptr(mine), ptr(m), ptr(v), c_i64(n), c_f32(1e-4),
+                  c_f32(0.9), c_f32(0.999), c_f32(1e-8), c_f32(5e-4), ptr(state), c_int(1), st)
+        norm = state.view(torch.float32)[3].item()
+        np.testing.assert_allclose(norm, float(total), rtol=1e-5)
+        np.testing.assert_allclose(mine.cpu().numpy(), ref.grad.cpu().numpy(), rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(flat.cpu().numpy(), ref.detach().cpu().numpy(), rtol=5e-7, atol=2e-7)   # 1-2 ulp
+    assert int(state[0]) == 4
