@@ -112,3 +112,36 @@ def test_retinanet_end_to_end(golden_dir, tag):
     np.testing.assert_allclose(s.numpy(), g['det_scores'], rtol=2e-4)
     assert (c.numpy() == g['det_classes']).mean() > 0.999
     np.testing.assert_allclose(b.numpy(), g['det_boxes'], rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize('tag', ['effdet_d0_128', 'effdet_d2_128x256'])
+def test_efficientdet_end_to_end(golden_dir, tag):
+    from oracle import ref_effdet
+    g = _load(golden_dir, 'e2e_%s.npz' % tag)
+    coef, (H, W), B, nc = int(g['coef']), g['hw'], int(g['batch']), int(g['num_classes'])
+    shapes = {str(k): tuple(int(v) for v in str(s).split(',') if v) for k, s in zip(g['state_keys'], g['state_shapes'])}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=float(g['gain']), head_std=float(g['head_std']))
+    p = {k: torch.from_numpy(v).requires_grad_(v.dtype == np.float32 and 'running' not in k)
+         for k, v in sd.items()}
+    img = torch.from_numpy(synth.synth_images(B, int(H), int(W), seed=1))
+    ann = torch.from_numpy(synth.synth_annotations(B, int(H), int(W), 6, 8, nc, seed=2))
+    cls, reg = ref_effdet.efficientdet_heads(p, img, coef, nc)
+    idx = g['head_idx']
+    np.testing.assert_allclose(cls.detach().numpy()[:, idx], g['cls_rows'], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(reg.detach().numpy()[:, idx], g['reg_rows'], rtol=1e-4, atol=1e-5)
+    anchors = torch.from_numpy(ref_cpu.anchors_for_image(int(H), int(W), **ref_effdet.ANCHOR_CFG))
+    cl, rl = ref_cpu.focal_loss(cls, reg, anchors, ann)
+    np.testing.assert_allclose(cl.detach().numpy(), g['cls_loss'], rtol=1e-5)
+    np.testing.assert_allclose(rl.detach().numpy(), g['reg_loss'], rtol=1e-5)
+    (cl.mean() + rl.mean()).backward()
+    for key in g.files:
+        if key.startswith('grad/') and key.endswith('/val'):
+            name = key[5:-4]
+            got = p[name].grad.reshape(-1)[torch.from_numpy(g['grad/%s/idx' % name])].numpy()
+            scale = float(g['grad/%s/norm' % name]) / np.sqrt(p[name].numel())
+            np.testing.assert_allclose(got, g[key], rtol=2e-3, atol=2e-3 * scale, err_msg=name)
+    with torch.no_grad():
+        s, c, b = ref_cpu.decode_tail(cls[:1].detach(), reg[:1].detach(), anchors, int(H), int(W))
+    assert s.shape == tuple(g['det_scores'].shape)
+    np.testing.assert_allclose(s.numpy(), g['det_scores'], rtol=1e-4)
+    np.testing.assert_allclose(b.numpy(), g['det_boxes'], rtol=1e-3, atol=1e-2)

@@ -287,8 +287,77 @@ def gen_e2e(depth, H, W, B, num_classes, tag, gain):
           'gnorm', d['grad_global_norm'])
 
 
+EFF_GRAD_KEYS = ['backbone_net.model._conv_stem.conv.weight', 'backbone_net.model._bn0.weight',
+                 'backbone_net.model._blocks.0._depthwise_conv.conv.weight',
+                 'backbone_net.model._blocks.0._se_reduce.conv.weight',
+                 'backbone_net.model._blocks.0._se_expand.conv.bias',
+                 'backbone_net.model._blocks.1._expand_conv.conv.weight',
+                 'backbone_net.model._blocks.2._bn1.bias',
+                 'backbone_net.model._blocks.5._project_conv.conv.weight',
+                 'backbone_net.model._blocks.15._depthwise_conv.conv.weight',
+                 'bifpn.0.p6_w1', 'bifpn.0.p4_w2', 'bifpn.1.p7_w2',
+                 'bifpn.0.p5_down_channel.0.conv.weight', 'bifpn.0.p5_to_p6.1.weight',
+                 'bifpn.0.conv6_up.depthwise_conv.conv.weight',
+                 'bifpn.1.conv4_down.pointwise_conv.conv.bias', 'bifpn.2.conv3_up.bn.weight',
+                 'regressor.conv_list.0.depthwise_conv.conv.weight',
+                 'regressor.conv_list.1.pointwise_conv.conv.weight', 'regressor.bn_list.3.1.bias',
+                 'regressor.header.pointwise_conv.conv.bias',
+                 'classifier.conv_list.2.pointwise_conv.conv.bias', 'classifier.bn_list.0.0.weight',
+                 'classifier.header.depthwise_conv.conv.weight',
+                 'classifier.header.pointwise_conv.conv.weight']
+
+
+def gen_e2e_effdet(coef, H, W, B, num_classes, tag, gain, head_std):
+    from architectures import efficientdet as ref_eff
+    torch.manual_seed(0)
+    model = ref_eff.build_efficientdet('efficientdet-d%d' % coef, num_classes=num_classes)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=gain, head_std=head_std)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    # deterministic path: frozen BN + drop-connect off (SURVEY.md 8c iii) == eval mode for
+    # every module whose behaviour depends on `training` (BatchNorm2d, MBConvBlock.drop_connect)
+    model.eval()
+    img = synth.synth_images(B, H, W, seed=1)
+    ann = synth.synth_annotations(B, H, W, num_real=6, pad_to=8, num_classes=num_classes, seed=2)
+    img_t, ann_t = torch.from_numpy(img), torch.from_numpy(ann)
+    feats = model.bifpn(tuple(model.backbone_net(img_t)[1:]))
+    reg = model.regressor(feats)
+    cls = model.classifier(feats)
+    cl, rl = model(img_t, ann_t)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+    d = dict(cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(), coef=np.array(coef),
+             hw=np.array([H, W]), batch=np.array(B), num_classes=np.array(num_classes),
+             gain=np.array(gain), head_std=np.array(head_std))
+    A = cls.shape[1]
+    idx = np.arange(0, A, 11)
+    d['head_idx'] = idx
+    d['cls_rows'] = cls.detach().numpy()[:, idx, :]
+    d['reg_rows'] = reg.detach().numpy()[:, idx, :]
+    for lvl, f in enumerate(feats):
+        d['feat%d_sample' % lvl] = f.detach().numpy()[:, ::7, ::3, ::3]
+    for k in EFF_GRAD_KEYS:
+        if k in grads:
+            g = grads[k]
+            d['grad/' + k + '/norm'] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            flat = g.reshape(-1)
+            sel = np.linspace(0, flat.size - 1, min(flat.size, 512)).astype(np.int64)
+            d['grad/' + k + '/idx'] = sel
+            d['grad/' + k + '/val'] = flat[sel]
+    d['grad_global_norm'] = np.array(np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in grads.values())))
+    d['state_keys'] = np.array(list(shapes.keys()))
+    d['state_shapes'] = np.array([','.join(map(str, shapes[k])) for k in shapes])
+    with torch.no_grad():
+        s, c, b = model(img_t[:1], return_loss=False)
+    d['det_scores'], d['det_classes'], d['det_boxes'] = s.numpy(), c.numpy(), b.numpy()
+    np.savez_compressed(os.path.join(OUT, 'e2e_%s.npz' % tag), **d)
+    print('e2e', tag, 'cls', cl.item(), 'reg', rl.item(), 'dets', s.shape, 'gnorm', d['grad_global_norm'],
+          'cls range', float(cls.min()), float(cls.max()))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['anchors', 'loss', 'decode', 'e2e']
+    which = sys.argv[1:] or ['anchors', 'loss', 'decode', 'e2e', 'effdet']
     if 'anchors' in which:
         gen_anchors()
     if 'loss' in which:
@@ -298,3 +367,6 @@ if __name__ == '__main__':
     if 'e2e' in which:
         gen_e2e(18, 256, 256, 2, 80, 'r18_256', 0.87)     # BASELINE.json configs[0]
         gen_e2e(50, 128, 160, 1, 20, 'r50_128x160', 0.78) # bottleneck path, ragged H != W
+    if 'effdet' in which:
+        gen_e2e_effdet(0, 128, 128, 2, 8, 'effdet_d0_128', 1.0, 0.05)      # configs[3] family
+        gen_e2e_effdet(2, 128, 256, 1, 5, 'effdet_d2_128x256', 1.0, 0.05)  # configs[4] family
