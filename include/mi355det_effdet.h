@@ -1,0 +1,84 @@
+/* mi355det — C ABI of the EfficientDet-specific HBM-bound kernels (gfx950).
+ *
+ * Depthwise / squeeze-excite / BiFPN pieces of architectures/efficientnet.py:80-115 (MBConvBlock),
+ * architectures/efficientdet.py:28-66 (SeparableConvBlock), :195-267 (BiFPN fast attention),
+ * architectures/utils_extra_efficientnet.py:9-96 (TF-"same" padding, zero-padded max-pool),
+ * architectures/utils_efficientnet.py:38-49 (swish forward / backward).  The 1x1 ("pointwise")
+ * convolutions run on the MFMA gather conv of mi355det_conv.h.
+ *
+ * Tensors are NHWC bf16 with C a multiple of 8.  A tensor flagged `in_swish` is stored as the
+ * PRE-activation z; its consumer applies swish(z) = z*sigmoid(z) while loading (the reference's
+ * MemoryEfficientSwish also keeps only z), and the matching backward multiplies by
+ * swish'(z) = s(z)*(1 + z*(1 - s(z))).
+ */
+#ifndef MI355DET_EFFDET_H_
+#define MI355DET_EFFDET_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* depthwise weights: fp32 [C][1][k][k] (contiguous) * scale[c] -> fp32 [k*k][C] (tap-major) */
+int mi355_dw_prep_weight(const float* w, const float* scale, int C, int k, float* w_t, void* stream);
+/* out[n,p,q,c] = bias[c] + sum_taps f(in[n, p*s - pad_t + r, q*s - pad_l + t, c]) * w_t[r*k+t][c],
+ * f = swish if in_swish else identity; zero padding (TF "same": pad_t/pad_l = extra/2). */
+int mi355_dwconv_fwd(const void* in, int in_swish, const float* w_t, const float* bias, void* out,
+                     int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
+                     void* stream);
+/* dx = conv-transpose(dy) [* swish'(zin) if zin] [+ dx if accumulate] */
+int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, const void* zin, int N, int H, int W,
+                       int C, int k, int stride, int pad_t, int pad_l, int P, int Q, int accumulate,
+                       void* stream);
+/* dw_t[t][c] += sum_m f(x)[m@t][c] * dy[m][c];  colsum[c] += sum_m dy[m][c] (may be NULL) */
+int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, float* dw_t, float* colsum, int N,
+                       int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
+                       void* stream);
+/* finish depthwise parameter grads: dW[c][k][k] (+)= G_t[t][c]*scale[c]; frozen-BN dgamma/dbeta
+ * (gamma may be NULL: plain conv). */
+int mi355_dw_param_grads(const float* G_t, const float* w, const float* scale, const float* colsum,
+                         const float* mean, const float* var, float eps, int C, int k, float* dW,
+                         float* dgamma, float* dbeta, int accumulate, void* stream);
+
+/* squeeze-excite (efficientnet.py:98-104) */
+int mi355_se_pool(const void* z, int in_swish, float* pool /* [N][C], zeroed */, int N, int HW, int C,
+                  void* stream);
+int mi355_se_fc(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2,
+                float* rpre /* [N][Cse] */, float* gate /* [N][C] */, int N, int C, int Cse, void* stream);
+int mi355_se_scale(const void* z, const float* gate, void* u, int N, int HW, int C, void* stream);
+int mi355_se_bwd_reduce(const void* gu, const void* z, float* ggate /* [N][C], zeroed */, int N, int HW,
+                        int C, void* stream);
+int mi355_se_fc_bwd(const float* pool, const float* w1, const float* w2, const float* rpre,
+                    const float* gate, const float* ggate, float* gpool, float* dw1, float* db1,
+                    float* dw2, float* db2, int N, int C, int Cse, void* stream);
+int mi355_se_bwd_apply(const void* gu, const void* z, const float* gate, const float* gpool, void* gz,
+                       int N, int HW, int C, void* stream);
+
+/* BiFPN fast-attention node (efficientdet.py:213-265): w = relu(p) / (sum relu(p) + eps) */
+int mi355_fusion_weights_fwd(const float* p, int n, float eps, float* w, void* stream);
+int mi355_fusion_weights_bwd(const float* p, int n, float eps, const float* gw, float* gp, void* stream);
+/* z = w[0]*in0 + w[1]*in1' + w[2]*in2; in1' = nearest-2x upsample of in1 when up1 != 0
+ * (in1 is then [N][H/2][W/2][C]); in2 may be NULL.  w: device float[3]. */
+int mi355_bifpn_node_fwd(const void* in0, const void* in1, int up1, const void* in2, const float* w,
+                         void* z, int N, int H, int W, int C, void* stream);
+/* gw[i] += <gz, in_i'> (device float[3], zeroed) */
+int mi355_bifpn_node_wgrad(const void* gz, const void* in0, const void* in1, int up1, const void* in2,
+                           float* gw, int N, int H, int W, int C, void* stream);
+/* dst (+)= w[wi] * src  (same shape, n elements) */
+int mi355_axpy_bf16(const void* src, const float* w, int wi, void* dst, int64_t n, int accumulate,
+                    void* stream);
+/* dst[N][H/2][W/2][C] (+)= w[wi] * (sum of the 2x2 children of src[N][H][W][C]) */
+int mi355_upsample_bwd_axpy(const void* src, const float* w, int wi, void* dst, int N, int H, int W, int C,
+                            int accumulate, void* stream);
+/* TF-"same" max-pool k=3 s=2 with ZERO padding taking part in the max
+ * (utils_extra_efficientnet.py:78-96); idx int8 = winning window slot, -1 = a pad won. */
+int mi355_maxpool_same_fwd(const void* in, void* out, int8_t* idx, int N, int H, int W, int C, void* stream);
+/* gin (+)= scatter(gout through idx) */
+int mi355_maxpool_same_bwd(const void* gout, const int8_t* idx, void* gin, int N, int H, int W, int C,
+                           int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355DET_EFFDET_H_ */

@@ -1,0 +1,722 @@
+// EfficientDet-specific HBM-bound kernels for gfx950: depthwise conv (TF-"same", fused frozen-BN
+// affine, swish applied on load), squeeze-excite, BiFPN fast-attention nodes, zero-padded "same"
+// max-pool.  NHWC bf16, 16 B (8 channels) per lane everywhere, fp32 math.
+//
+// Reference arithmetic: architectures/efficientnet.py:80-115, architectures/efficientdet.py:28-66,
+// :195-267, architectures/utils_extra_efficientnet.py:9-96, architectures/utils_efficientnet.py:38-49.
+#include "conv_common.h"
+#include "mi355det_effdet.h"
+
+using namespace mi355;
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float swishf(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float dswishf(float x) {          // utils_efficientnet.py:46-49
+    const float s = sigmoidf_(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ void load8(const unsigned short* p, float v[8]) {
+    const s8v t = *reinterpret_cast<const s8v*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((unsigned short)t[e]);
+}
+__device__ __forceinline__ void store8(unsigned short* p, const float v[8]) {
+    s8v t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (short)f32_to_bf16_rn(v[e]);
+    *reinterpret_cast<s8v*>(p) = t;
+}
+inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+// ============================================================================ depthwise conv
+__global__ void dw_prep_weight_kernel(const float* __restrict__ w, const float* __restrict__ scale, int C,
+                                      int T, float* __restrict__ w_t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * T) return;
+    const int t = i / C, c = i - t * C;
+    w_t[i] = w[c * T + t] * (scale ? scale[c] : 1.0f);
+}
+
+extern "C" int mi355_dw_prep_weight(const float* w, const float* scale, int C, int k, float* w_t, void* stream) {
+    MI355_REQUIRE(w && w_t && C > 0 && k > 0, "dw_prep_weight: bad args");
+    hipLaunchKernelGGL(dw_prep_weight_kernel, dim3(blocks_for((long long)C * k * k)), dim3(256), 0,
+                       (hipStream_t)stream, w, scale, C, k * k, w_t);
+    return check_launch("dw_prep_weight_kernel");
+}
+
+template <bool SWISH>
+__global__ void dwconv_fwd_kernel(const unsigned short* __restrict__ in, const float* __restrict__ w_t,
+                                  const float* __restrict__ bias, unsigned short* __restrict__ out, int N, int H,
+                                  int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q) {
+    const int c8n = C >> 3;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * P * Q * c8n) return;
+    const int c8 = (int)(t % c8n);
+    long long r = t / c8n;
+    const int q = (int)(r % Q);  r /= Q;
+    const int p = (int)(r % P);
+    const int n = (int)(r / P);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[c8 * 8 + e] : 0.0f;
+    for (int a = 0; a < k; ++a) {
+        const int h = p * stride - pad_t + a;
+        if ((unsigned)h >= (unsigned)H) continue;
+        for (int b = 0; b < k; ++b) {
+            const int w = q * stride - pad_l + b;
+            if ((unsigned)w >= (unsigned)W) continue;
+            float x[8];
+            load8(in + (((long long)n * H + h) * W + w) * C + c8 * 8, x);
+            const float* wt = w_t + (a * k + b) * C + c8 * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (SWISH ? swishf(x[e]) : x[e]) * wt[e];
+        }
+    }
+    store8(out + t * 8, acc);
+}
+
+extern "C" int mi355_dwconv_fwd(const void* in, int in_swish, const float* w_t, const float* bias, void* out,
+                                int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
+                                void* stream) {
+    MI355_REQUIRE(in && w_t && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && k > 0 && stride > 0,
+                  "dwconv_fwd: bad args");
+    const long long total = (long long)N * P * Q * (C / 8);
+    if (in_swish)
+        hipLaunchKernelGGL(dwconv_fwd_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)in, w_t, bias, (unsigned short*)out, N, H, W, C, k, stride,
+                           pad_t, pad_l, P, Q);
+    else
+        hipLaunchKernelGGL(dwconv_fwd_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)in, w_t, bias, (unsigned short*)out, N, H, W, C, k, stride,
+                           pad_t, pad_l, P, Q);
+    return check_launch("dwconv_fwd_kernel");
+}
+
+__global__ void dwconv_dgrad_kernel(const unsigned short* __restrict__ dy, const float* __restrict__ w_t,
+                                    unsigned short* __restrict__ dx, const unsigned short* __restrict__ zin, int N,
+                                    int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
+                                    int accumulate) {
+    const int c8n = C >> 3;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * H * W * c8n) return;
+    const int c8 = (int)(t % c8n);
+    long long r = t / c8n;
+    const int w = (int)(r % W);  r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = 0; a < k; ++a) {
+        const int hp = h + pad_t - a;
+        if (hp < 0 || hp % stride) continue;
+        const int p = hp / stride;
+        if (p >= P) continue;
+        for (int b = 0; b < k; ++b) {
+            const int wq = w + pad_l - b;
+            if (wq < 0 || wq % stride) continue;
+            const int q = wq / stride;
+            if (q >= Q) continue;
+            float g[8];
+            load8(dy + (((long long)n * P + p) * Q + q) * C + c8 * 8, g);
+            const float* wt = w_t + (a * k + b) * C + c8 * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += g[e] * wt[e];
+        }
+    }
+    if (zin) {
+        float z[8];
+        load8(zin + t * 8, z);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] *= dswishf(z[e]);
+    }
+    if (accumulate) {
+        float o[8];
+        load8(dx + t * 8, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += o[e];
+    }
+    store8(dx + t * 8, acc);
+}
+
+extern "C" int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, const void* zin, int N, int H,
+                                  int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
+                                  int accumulate, void* stream) {
+    MI355_REQUIRE(dy && w_t && dx && N > 0 && C > 0 && C % 8 == 0 && k > 0 && stride > 0, "dwconv_dgrad: bad args");
+    const long long total = (long long)N * H * W * (C / 8);
+    hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)dy, w_t, (unsigned short*)dx, (const unsigned short*)zin, N, H, W, C,
+                       k, stride, pad_t, pad_l, P, Q, accumulate);
+    return check_launch("dwconv_dgrad_kernel");
+}
+
+// thread = (tap, 8-channel chunk); block.y = pixel chunk.  8 accumulators per thread.
+template <bool SWISH>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(
+    const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy, float* __restrict__ dw_t,
+    float* __restrict__ colsum, int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
+    int rows_per_block) {
+    const int c8n = C >> 3, T = k * k;
+    const int item = blockIdx.x * 256 + threadIdx.x;           // (tap, c8)
+    if (item >= T * c8n) return;
+    const int tap = item / c8n, c8 = item - tap * c8n;
+    const int a = tap / k, b = tap - a * k;
+    const long long M = (long long)N * P * Q;
+    const long long m0 = (long long)blockIdx.y * rows_per_block;
+    const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long m = m0; m < m1; ++m) {
+        const int q = (int)(m % Q);
+        const long long r = m / Q;
+        const int p = (int)(r % P), n = (int)(r / P);
+        float g[8];
+        load8(dy + m * C + c8 * 8, g);
+        if (colsum && tap == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[e] += g[e];
+        }
+        const int h = p * stride - pad_t + a, w = q * stride - pad_l + b;
+        if ((unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) continue;
+        float v[8];
+        load8(x + (((long long)n * H + h) * W + w) * C + c8 * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (SWISH ? swishf(v[e]) : v[e]) * g[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(dw_t + tap * C + c8 * 8 + e, acc[e]);
+    if (colsum && tap == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(colsum + c8 * 8 + e, cs[e]);
+    }
+}
+
+extern "C" int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, float* dw_t, float* colsum, int N,
+                                  int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
+                                  void* stream) {
+    MI355_REQUIRE(x && dy && dw_t && N > 0 && C > 0 && C % 8 == 0 && k > 0, "dwconv_wgrad: bad args");
+    const long long M = (long long)N * P * Q;
+    const int items = k * k * (C / 8);
+    const int bx = (items + 255) / 256;
+    long long chunks = 2048 / bx;                         // ~2048 blocks in flight
+    if (chunks < 1) chunks = 1;
+    long long rows = (M + chunks - 1) / chunks;
+    if (rows < 32) rows = 32;
+    const long long by = (M + rows - 1) / rows;
+    MI355_REQUIRE(by <= 65535, "dwconv_wgrad: grid");
+    dim3 grid((unsigned)bx, (unsigned)by);
+    if (in_swish)
+        hipLaunchKernelGGL(dwconv_wgrad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)x, (const unsigned short*)dy, dw_t, colsum, N, H, W, C, k, stride,
+                           pad_t, pad_l, P, Q, (int)rows);
+    else
+        hipLaunchKernelGGL(dwconv_wgrad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)x, (const unsigned short*)dy, dw_t, colsum, N, H, W, C, k, stride,
+                           pad_t, pad_l, P, Q, (int)rows);
+    return check_launch("dwconv_wgrad_kernel");
+}
+
+__global__ void dw_param_grads_kernel(const float* __restrict__ G_t, const float* __restrict__ w,
+                                      const float* __restrict__ scale, const float* __restrict__ colsum,
+                                      const float* __restrict__ mean, const float* __restrict__ var, float eps, int C,
+                                      int T, float* __restrict__ dW, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = scale ? scale[c] : 1.0f;
+    float dot = 0.0f;
+    for (int t = 0; t < T; ++t) {
+        const float g = G_t[t * C + c];
+        dot += w[c * T + t] * g;
+        const float d = g * sc;
+        dW[c * T + t] = accumulate ? dW[c * T + t] + d : d;
+    }
+    if (dgamma) {
+        const float dg = (1.0f / sqrtf(var[c] + eps)) * (dot - mean[c] * colsum[c]);
+        dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+    }
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + colsum[c] : colsum[c];
+}
+
+extern "C" int mi355_dw_param_grads(const float* G_t, const float* w, const float* scale, const float* colsum,
+                                    const float* mean, const float* var, float eps, int C, int k, float* dW,
+                                    float* dgamma, float* dbeta, int accumulate, void* stream) {
+    MI355_REQUIRE(G_t && w && dW && C > 0 && k > 0, "dw_param_grads: bad args");
+    MI355_REQUIRE(!(dgamma || dbeta) || colsum, "dw_param_grads: colsum needed");
+    MI355_REQUIRE(!dgamma || (mean && var), "dw_param_grads: mean/var needed");
+    hipLaunchKernelGGL(dw_param_grads_kernel, dim3(blocks_for(C)), dim3(256), 0, (hipStream_t)stream, G_t, w, scale,
+                       colsum, mean, var, eps, C, k * k, dW, dgamma, dbeta, accumulate);
+    return check_launch("dw_param_grads_kernel");
+}
+
+// ============================================================================ squeeze-excite
+// pool[n][c] += (1/HW) * sum over a slab of pixels; grid (slabs, N)
+template <bool SWISH, bool MUL>
+__global__ __launch_bounds__(256) void se_reduce_kernel(const unsigned short* __restrict__ a,
+                                                        const unsigned short* __restrict__ z, float* __restrict__ out,
+                                                        int HW, int C, int rows_per_block, float scale) {
+    __shared__ float s_acc[2048 + 8];
+    const int c8n = C >> 3;
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int nphase = 256 / c8n > 0 ? 256 / c8n : 1;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(HW, r0 + rows_per_block);
+    for (int cb = 0; cb < c8n; cb += 256) {                     // C/8 may exceed 256 (C up to 2112)
+        const int c8 = cb + (tid % min(c8n, 256));
+        const int ph = tid / min(c8n, 256);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (c8 < c8n && ph < nphase) {
+            for (int m = r0 + ph; m < r1; m += nphase) {
+                float v[8];
+                load8(z + ((long long)n * HW + m) * C + c8 * 8, v);
+                if (MUL) {
+                    float g[8];
+                    load8(a + ((long long)n * HW + m) * C + c8 * 8, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += g[e] * (SWISH ? swishf(v[e]) : v[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += SWISH ? swishf(v[e]) : v[e];
+                }
+            }
+        }
+        if (c8n <= 256) {
+            if (c8 < c8n && ph < nphase) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s_acc[ph * C + c8 * 8 + e] = acc[e];
+            }
+            __syncthreads();
+            for (int c = tid; c < C; c += 256) {
+                float t = 0.0f;
+                for (int r = 0; r < nphase; ++r) t += s_acc[r * C + c];
+                atomicAdd(out + (long long)n * C + c, t * scale);
+            }
+            __syncthreads();
+        } else if (c8 < c8n) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(out + (long long)n * C + c8 * 8 + e, acc[e] * scale);
+        }
+    }
+}
+
+static void se_grid(int N, int HW, int* rows, dim3* grid) {
+    int slabs = (HW + 2047) / 2048;
+    if (slabs < 1) slabs = 1;
+    *rows = (HW + slabs - 1) / slabs;
+    *grid = dim3((unsigned)slabs, (unsigned)N);
+}
+
+extern "C" int mi355_se_pool(const void* z, int in_swish, float* pool, int N, int HW, int C, void* stream) {
+    MI355_REQUIRE(z && pool && N > 0 && N <= 65535 && HW > 0 && C > 0 && C % 8 == 0, "se_pool: bad args");
+    int rows; dim3 grid;
+    se_grid(N, HW, &rows, &grid);
+    const float sc = 1.0f / (float)HW;
+    if (in_swish)
+        hipLaunchKernelGGL((se_reduce_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, nullptr,
+                           (const unsigned short*)z, pool, HW, C, rows, sc);
+    else
+        hipLaunchKernelGGL((se_reduce_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, nullptr,
+                           (const unsigned short*)z, pool, HW, C, rows, sc);
+    return check_launch("se_pool");
+}
+
+extern "C" int mi355_se_bwd_reduce(const void* gu, const void* z, float* ggate, int N, int HW, int C, void* stream) {
+    MI355_REQUIRE(gu && z && ggate && N > 0 && N <= 65535 && HW > 0 && C > 0 && C % 8 == 0, "se_bwd_reduce: bad args");
+    int rows; dim3 grid;
+    se_grid(N, HW, &rows, &grid);
+    hipLaunchKernelGGL((se_reduce_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)gu, (const unsigned short*)z, ggate, HW, C, rows, 1.0f);
+    return check_launch("se_bwd_reduce");
+}
+
+// one block per sample: r = swish(W1 pool + b1); gate = sigmoid(W2 r + b2)
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
+                                                    const float* __restrict__ b1, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, float* __restrict__ rpre,
+                                                    float* __restrict__ gate, int C, int Cse) {
+    extern __shared__ float sm[];                  // pool[C] | r[Cse]
+    float* s_pool = sm;
+    float* s_r = sm + C;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) s_pool[c] = pool[(long long)n * C + c];
+    __syncthreads();
+    for (int j = tid; j < Cse; j += 256) {
+        float t = b1[j];
+        for (int c = 0; c < C; ++c) t += w1[j * C + c] * s_pool[c];
+        rpre[(long long)n * Cse + j] = t;
+        s_r[j] = swishf(t);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float t = b2[c];
+        for (int j = 0; j < Cse; ++j) t += w2[c * Cse + j] * s_r[j];
+        gate[(long long)n * C + c] = sigmoidf_(t);
+    }
+}
+
+extern "C" int mi355_se_fc(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2,
+                           float* rpre, float* gate, int N, int C, int Cse, void* stream) {
+    MI355_REQUIRE(pool && w1 && b1 && w2 && b2 && rpre && gate && N > 0 && C > 0 && Cse > 0, "se_fc: bad args");
+    hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), (size_t)(C + Cse) * 4, (hipStream_t)stream, pool, w1, b1, w2,
+                       b2, rpre, gate, C, Cse);
+    return check_launch("se_fc_kernel");
+}
+
+__global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
+                                                        const float* __restrict__ w2, const float* __restrict__ rpre,
+                                                        const float* __restrict__ gate, const float* __restrict__ ggate,
+                                                        float* __restrict__ gpool, float* __restrict__ dw1,
+                                                        float* __restrict__ db1, float* __restrict__ dw2,
+                                                        float* __restrict__ db2, int C, int Cse) {
+    extern __shared__ float sm[];                  // pool[C] | de[C] | r[Cse] | drpre[Cse]
+    float* s_pool = sm;
+    float* s_de = sm + C;
+    float* s_r = sm + 2 * C;
+    float* s_dr = sm + 2 * C + Cse;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        s_pool[c] = pool[(long long)n * C + c];
+        const float g = gate[(long long)n * C + c];
+        const float de = ggate[(long long)n * C + c] * g * (1.0f - g);
+        s_de[c] = de;
+        atomicAdd(db2 + c, de);
+    }
+    for (int j = tid; j < Cse; j += 256) s_r[j] = swishf(rpre[(long long)n * Cse + j]);
+    __syncthreads();
+    for (int i = tid; i < C * Cse; i += 256) {
+        const int c = i / Cse, j = i - c * Cse;
+        atomicAdd(dw2 + i, s_de[c] * s_r[j]);
+    }
+    for (int j = tid; j < Cse; j += 256) {
+        float t = 0.0f;
+        for (int c = 0; c < C; ++c) t += w2[c * Cse + j] * s_de[c];
+        const float d = t * dswishf(rpre[(long long)n * Cse + j]);
+        s_dr[j] = d;
+        atomicAdd(db1 + j, d);
+    }
+    __syncthreads();
+    for (int i = tid; i < Cse * C; i += 256) {
+        const int j = i / C, c = i - j * C;
+        atomicAdd(dw1 + i, s_dr[j] * s_pool[c]);
+    }
+    for (int c = tid; c < C; c += 256) {
+        float t = 0.0f;
+        for (int j = 0; j < Cse; ++j) t += w1[j * C + c] * s_dr[j];
+        gpool[(long long)n * C + c] = t;
+    }
+}
+
+extern "C" int mi355_se_fc_bwd(const float* pool, const float* w1, const float* w2, const float* rpre,
+                               const float* gate, const float* ggate, float* gpool, float* dw1, float* db1,
+                               float* dw2, float* db2, int N, int C, int Cse, void* stream) {
+    MI355_REQUIRE(pool && w1 && w2 && rpre && gate && ggate && gpool && dw1 && db1 && dw2 && db2 && N > 0 && C > 0 &&
+                  Cse > 0, "se_fc_bwd: bad args");
+    hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(N), dim3(256), (size_t)(2 * C + 2 * Cse) * 4, (hipStream_t)stream, pool,
+                       w1, w2, rpre, gate, ggate, gpool, dw1, db1, dw2, db2, C, Cse);
+    return check_launch("se_fc_bwd_kernel");
+}
+
+__global__ void se_scale_kernel(const unsigned short* __restrict__ z, const float* __restrict__ gate,
+                                unsigned short* __restrict__ u, long long total, int HW, int C) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c8n = C >> 3;
+    const int c8 = (int)(t % c8n);
+    const long long n = t / ((long long)c8n * HW);
+    float v[8];
+    load8(z + t * 8, v);
+    const float* g = gate + n * C + c8 * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = swishf(v[e]) * g[e];
+    store8(u + t * 8, v);
+}
+
+extern "C" int mi355_se_scale(const void* z, const float* gate, void* u, int N, int HW, int C, void* stream) {
+    MI355_REQUIRE(z && gate && u && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_scale: bad args");
+    const long long total = (long long)N * HW * (C / 8);
+    hipLaunchKernelGGL(se_scale_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)z, gate, (unsigned short*)u, total, HW, C);
+    return check_launch("se_scale_kernel");
+}
+
+__global__ void se_bwd_apply_kernel(const unsigned short* __restrict__ gu, const unsigned short* __restrict__ z,
+                                    const float* __restrict__ gate, const float* __restrict__ gpool,
+                                    unsigned short* __restrict__ gz, long long total, int HW, int C) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c8n = C >> 3;
+    const int c8 = (int)(t % c8n);
+    const long long n = t / ((long long)c8n * HW);
+    float g[8], v[8];
+    load8(gu + t * 8, g);
+    load8(z + t * 8, v);
+    const float* ga = gate + n * C + c8 * 8;
+    const float* gp = gpool + n * C + c8 * 8;
+    const float inv = 1.0f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = (g[e] * ga[e] + gp[e] * inv) * dswishf(v[e]);
+    store8(gz + t * 8, g);
+}
+
+extern "C" int mi355_se_bwd_apply(const void* gu, const void* z, const float* gate, const float* gpool, void* gz,
+                                  int N, int HW, int C, void* stream) {
+    MI355_REQUIRE(gu && z && gate && gpool && gz && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_bwd_apply: bad args");
+    const long long total = (long long)N * HW * (C / 8);
+    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)gu, (const unsigned short*)z, gate, gpool, (unsigned short*)gz, total, HW, C);
+    return check_launch("se_bwd_apply_kernel");
+}
+
+// ============================================================================ BiFPN
+__global__ void fusion_weights_fwd_kernel(const float* p, int n, float eps, float* w) {
+    if (threadIdx.x != 0) return;
+    float s = 0.0f;
+    for (int i = 0; i < n; ++i) s += fmaxf(p[i], 0.0f);
+    for (int i = 0; i < 3; ++i) w[i] = i < n ? fmaxf(p[i], 0.0f) / (s + eps) : 0.0f;
+}
+extern "C" int mi355_fusion_weights_fwd(const float* p, int n, float eps, float* w, void* stream) {
+    MI355_REQUIRE(p && w && n >= 1 && n <= 3, "fusion_weights_fwd: bad args");
+    hipLaunchKernelGGL(fusion_weights_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, n, eps, w);
+    return check_launch("fusion_weights_fwd_kernel");
+}
+__global__ void fusion_weights_bwd_kernel(const float* p, int n, float eps, const float* gw, float* gp) {
+    if (threadIdx.x != 0) return;
+    float s = eps, dot = 0.0f;
+    for (int i = 0; i < n; ++i) { const float r = fmaxf(p[i], 0.0f); s += r; dot += gw[i] * r; }
+    // w_i = r_i / s  ->  dL/dr_j = gw_j / s - dot / s^2 ; relu'
+    for (int j = 0; j < n; ++j) gp[j] = p[j] > 0.0f ? (gw[j] / s - dot / (s * s)) : 0.0f;
+}
+extern "C" int mi355_fusion_weights_bwd(const float* p, int n, float eps, const float* gw, float* gp, void* stream) {
+    MI355_REQUIRE(p && gw && gp && n >= 1 && n <= 3, "fusion_weights_bwd: bad args");
+    hipLaunchKernelGGL(fusion_weights_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, n, eps, gw, gp);
+    return check_launch("fusion_weights_bwd_kernel");
+}
+
+template <bool WGRAD>
+__global__ __launch_bounds__(256) void bifpn_node_kernel(const unsigned short* __restrict__ gz,
+                                                         const unsigned short* __restrict__ in0,
+                                                         const unsigned short* __restrict__ in1, int up1,
+                                                         const unsigned short* __restrict__ in2,
+                                                         const float* __restrict__ w, unsigned short* __restrict__ z,
+                                                         float* __restrict__ gw, int N, int H, int W, int C) {
+    const int c8n = C >> 3;
+    const long long total = (long long)N * H * W * c8n;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (t < total) {
+        const int c8 = (int)(t % c8n);
+        long long r = t / c8n;
+        const int x = (int)(r % W);  r /= W;
+        const int y = (int)(r % H);
+        const int n = (int)(r / H);
+        float a[8], b[8], c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        load8(in0 + t * 8, a);
+        const long long o1 = up1 ? ((((long long)n * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C + c8 * 8) : t * 8;
+        load8(in1 + o1, b);
+        if (in2) load8(in2 + t * 8, c);
+        if (WGRAD) {
+            float g[8];
+            load8(gz + t * 8, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { d0 += g[e] * a[e]; d1 += g[e] * b[e]; d2 += g[e] * c[e]; }
+        } else {
+            const float w0 = w[0], w1 = w[1], w2 = w[2];
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = w0 * a[e] + w1 * b[e] + w2 * c[e];
+            store8(z + t * 8, o);
+        }
+    }
+    if (WGRAD) {
+        __shared__ float red[3][4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            d0 += __shfl_down(d0, o, 64); d1 += __shfl_down(d1, o, 64); d2 += __shfl_down(d2, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d0; red[1][threadIdx.x >> 6] = d1; red[2][threadIdx.x >> 6] = d2; }
+        __syncthreads();
+        if (threadIdx.x < 3) atomicAdd(gw + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
+}
+
+extern "C" int mi355_bifpn_node_fwd(const void* in0, const void* in1, int up1, const void* in2, const float* w,
+                                    void* z, int N, int H, int W, int C, void* stream) {
+    MI355_REQUIRE(in0 && in1 && w && z && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bifpn_node_fwd: bad args");
+    MI355_REQUIRE(!up1 || (H % 2 == 0 && W % 2 == 0), "bifpn_node_fwd: upsample needs even H, W");
+    const long long total = (long long)N * H * W * (C / 8);
+    hipLaunchKernelGGL(bifpn_node_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, nullptr,
+                       (const unsigned short*)in0, (const unsigned short*)in1, up1, (const unsigned short*)in2, w,
+                       (unsigned short*)z, nullptr, N, H, W, C);
+    return check_launch("bifpn_node_kernel<fwd>");
+}
+
+extern "C" int mi355_bifpn_node_wgrad(const void* gz, const void* in0, const void* in1, int up1, const void* in2,
+                                      float* gw, int N, int H, int W, int C, void* stream) {
+    MI355_REQUIRE(gz && in0 && in1 && gw && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bifpn_node_wgrad: bad args");
+    const long long total = (long long)N * H * W * (C / 8);
+    hipLaunchKernelGGL(bifpn_node_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)gz, (const unsigned short*)in0, (const unsigned short*)in1, up1,
+                       (const unsigned short*)in2, nullptr, nullptr, gw, N, H, W, C);
+    return check_launch("bifpn_node_kernel<wgrad>");
+}
+
+__global__ void axpy_kernel(const unsigned short* __restrict__ src, const float* __restrict__ w, int wi,
+                            unsigned short* __restrict__ dst, long long n8, int accumulate) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n8) return;
+    const float a = w ? w[wi] : 1.0f;
+    float v[8], o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    load8(src + t * 8, v);
+    if (accumulate) load8(dst + t * 8, o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] += a * v[e];
+    store8(dst + t * 8, o);
+}
+
+extern "C" int mi355_axpy_bf16(const void* src, const float* w, int wi, void* dst, int64_t n, int accumulate,
+                               void* stream) {
+    MI355_REQUIRE(src && dst && n > 0 && n % 8 == 0, "axpy: n must be a multiple of 8");
+    hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, w, wi, (unsigned short*)dst, (long long)(n / 8), accumulate);
+    return check_launch("axpy_kernel");
+}
+
+__global__ void upsample_bwd_axpy_kernel(const unsigned short* __restrict__ src, const float* __restrict__ w, int wi,
+                                         unsigned short* __restrict__ dst, int N, int H, int W, int C, int accumulate) {
+    const int c8n = C >> 3, P = H >> 1, Q = W >> 1;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * P * Q * c8n) return;
+    const int c8 = (int)(t % c8n);
+    long long r = t / c8n;
+    const int q = (int)(r % Q);  r /= Q;
+    const int p = (int)(r % P);
+    const int n = (int)(r / P);
+    const float a = w ? w[wi] : 1.0f;
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (accumulate) load8(dst + t * 8, o);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[8];
+            load8(src + (((long long)n * H + 2 * p + i) * W + 2 * q + j) * C + c8 * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v[e];
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] += a * acc[e];
+    store8(dst + t * 8, o);
+}
+
+extern "C" int mi355_upsample_bwd_axpy(const void* src, const float* w, int wi, void* dst, int N, int H, int W, int C,
+                                       int accumulate, void* stream) {
+    MI355_REQUIRE(src && dst && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0,
+                  "upsample_bwd_axpy: bad args");
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(upsample_bwd_axpy_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)src, w, wi, (unsigned short*)dst, N, H, W, C, accumulate);
+    return check_launch("upsample_bwd_axpy_kernel");
+}
+
+// ============================================================================ "same" max-pool (k3 s2)
+static void same_pad(int n, int k, int s, int* before, int* out) {
+    *out = (n + s - 1) / s;
+    const int extra = s * (*out - 1) + 1 + (k - 1) - n;
+    *before = extra / 2;
+}
+
+__global__ void maxpool_same_fwd_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
+                                        signed char* __restrict__ idx, int N, int H, int W, int C, int P, int Q,
+                                        int pad_t, int pad_l) {
+    const int c8n = C >> 3;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * P * Q * c8n) return;
+    const int c8 = (int)(t % c8n);
+    long long r = t / c8n;
+    const int q = (int)(r % Q);  r /= Q;
+    const int p = (int)(r % P);
+    const int n = (int)(r / P);
+    float best[8];
+    int bi[8];
+    bool first = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int h = 2 * p - pad_t + a, w = 2 * q - pad_l + b;
+            const bool inb = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};                 // zero padding takes part in the max
+            if (inb) load8(in + (((long long)n * H + h) * W + w) * C + c8 * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (first || v[e] > best[e]) { best[e] = v[e]; bi[e] = inb ? a * 3 + b : -1; }
+            first = false;
+        }
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) packed |= (unsigned long long)(bi[e] & 0xff) << (8 * e);
+    store8(out + t * 8, best);
+    *reinterpret_cast<unsigned long long*>(idx + t * 8) = packed;
+}
+
+extern "C" int mi355_maxpool_same_fwd(const void* in, void* out, int8_t* idx, int N, int H, int W, int C,
+                                      void* stream) {
+    MI355_REQUIRE(in && out && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_same_fwd: bad args");
+    int pt, pl, P, Q;
+    same_pad(H, 3, 2, &pt, &P);
+    same_pad(W, 3, 2, &pl, &Q);
+    const long long total = (long long)N * P * Q * (C / 8);
+    hipLaunchKernelGGL(maxpool_same_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)in, (unsigned short*)out, (signed char*)idx, N, H, W, C, P, Q, pt, pl);
+    return check_launch("maxpool_same_fwd_kernel");
+}
+
+__global__ void maxpool_same_bwd_kernel(const unsigned short* __restrict__ gout, const signed char* __restrict__ idx,
+                                        unsigned short* __restrict__ gin, int N, int H, int W, int C, int P, int Q,
+                                        int pad_t, int pad_l, int accumulate) {
+    const int c8n = C >> 3;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * H * W * c8n) return;
+    const int c8 = (int)(t % c8n);
+    long long r = t / c8n;
+    const int w = (int)(r % W);  r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (accumulate) load8(gin + t * 8, acc);
+    for (int a = 0; a < 3; ++a) {
+        const int hp = h + pad_t - a;
+        if (hp < 0 || (hp & 1)) continue;
+        const int p = hp >> 1;
+        if (p >= P) continue;
+        for (int b = 0; b < 3; ++b) {
+            const int wq = w + pad_l - b;
+            if (wq < 0 || (wq & 1)) continue;
+            const int q = wq >> 1;
+            if (q >= Q) continue;
+            const long long o = (((long long)n * P + p) * Q + q) * C + c8 * 8;
+            const unsigned long long pk = *reinterpret_cast<const unsigned long long*>(idx + o);
+            float g[8];
+            load8(gout + o, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if ((int)(signed char)((pk >> (8 * e)) & 0xff) == a * 3 + b) acc[e] += g[e];
+        }
+    }
+    store8(gin + t * 8, acc);
+}
+
+extern "C" int mi355_maxpool_same_bwd(const void* gout, const int8_t* idx, void* gin, int N, int H, int W, int C,
+                                      int accumulate, void* stream) {
+    MI355_REQUIRE(gout && idx && gin && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_same_bwd: bad args");
+    int pt, pl, P, Q;
+    same_pad(H, 3, 2, &pt, &P);
+    same_pad(W, 3, 2, &pl, &Q);
+    const long long total = (long long)N * H * W * (C / 8);
+    hipLaunchKernelGGL(maxpool_same_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)gout, (const signed char*)idx, (unsigned short*)gin, N, H, W, C, P, Q, pt,
+                       pl, accumulate);
+    return check_launch("maxpool_same_bwd_kernel");
+}

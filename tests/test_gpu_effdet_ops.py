@@ -1,0 +1,154 @@
+"""GPU parity of the EfficientDet HBM-bound kernels (through the C ABI) vs torch fp32 on the same
+bf16-rounded inputs: depthwise TF-"same" conv fwd / dgrad / wgrad with swish-on-load, squeeze-excite
+forward / backward, BiFPN node + fusion weights, zero-padded "same" max-pool."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_effdet as R
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _mk(shape, seed, scale=1.0):
+    return _bf(torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale)
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
+
+
+def _close(got, ref, tol):
+    got, ref = got.float().cpu(), ref.float()
+    err = (got - ref).abs().max().item()
+    mag = ref.abs().max().item() + 1e-12
+    assert err <= tol * mag, 'max err %.4g vs magnitude %.4g (tol %.3g)' % (err, mag, tol)
+
+
+@pytest.mark.parametrize('N,H,W,C,k,s,sw', [(2, 16, 20, 32, 3, 1, True), (2, 17, 21, 24, 3, 2, True),
+                                            (1, 16, 16, 40, 5, 2, True), (2, 9, 7, 64, 5, 1, False),
+                                            (1, 8, 8, 264 * 8, 3, 1, True)])
+def test_depthwise_conv(N, H, W, C, k, s, sw):
+    from objectdetection.pytorch_amd import ops_effdet as E
+    z = _mk((N, C, H, W), 1).requires_grad_(True)
+    w = _mk((C, 1, k, k), 2, 0.3).float().requires_grad_(True)
+    scale = torch.rand(C, generator=torch.Generator().manual_seed(3)) + 0.5
+    shift = torch.randn(C, generator=torch.Generator().manual_seed(4)) * 0.1
+    x = R.swish(z) if sw else z
+    y = R.conv_same(x, w * scale[:, None, None, None], None, s, C) + shift[None, :, None, None]
+    gy = _mk(tuple(y.shape), 5)
+    y.backward(gy)
+    w_t = torch.empty((k * k, C), device=DEV)
+    E.dw_prep_weight(w.detach().to(DEV).contiguous(), scale.to(DEV), w_t)
+    zh = _nhwc(z.detach())
+    out = E.dwconv_fwd(zh, sw, w_t, shift.to(DEV), k, s)
+    _close(out.permute(0, 3, 1, 2), y.detach(), 1e-2)
+    gyh = _nhwc(gy)
+    dx = E.dwconv_dgrad(gyh, w_t, tuple(zh.shape), k, s, zin=zh if sw else None)
+    _close(dx.permute(0, 3, 1, 2), z.grad, 1.5e-2)
+    dw_t = torch.zeros((k * k, C), device=DEV)
+    cs = torch.zeros(C, device=DEV)
+    E.dwconv_wgrad(zh, sw, gyh, dw_t, cs, k, s)
+    # raw wgrad G (w.r.t. the scaled weight) = dL/dw / scale
+    _close(dw_t.t().reshape(C, 1, k, k) * scale.to(DEV)[:, None, None, None], w.grad, 5e-3)
+    _close(cs, gy.sum((0, 2, 3)), 2e-3)
+
+
+def test_maxpool_same_zero_padding():
+    from objectdetection.pytorch_amd import ops_effdet as E
+    for (H, W) in ((16, 16), (9, 11), (8, 6)):
+        x = _bf(_mk((2, 16, H, W), H) - 1.0).requires_grad_(True)    # mostly negative: pads (0) win
+        y = R.maxpool_same(x)
+        gy = _mk(tuple(y.shape), 3)
+        y.backward(gy)
+        out, idx = E.maxpool_same_fwd(_nhwc(x.detach()))
+        assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), y.detach())
+        gin = torch.zeros((2, H, W, 16), dtype=torch.bfloat16, device=DEV)
+        E.maxpool_same_bwd(_nhwc(gy), idx, gin, False)
+        _close(gin.permute(0, 3, 1, 2), x.grad, 1e-2)
+
+
+def test_squeeze_excite_fwd_bwd():
+    from objectdetection.pytorch_amd._lib import call, ptr, c_int, stream_of
+    N, C, Cse, H, W = 3, 96, 4, 12, 10
+    z = _mk((N, C, H, W), 1).requires_grad_(True)
+    w1 = (_mk((Cse, C, 1, 1), 2, 0.2)).float().requires_grad_(True)
+    b1 = _mk((Cse,), 3, 0.1).float().requires_grad_(True)
+    w2 = (_mk((C, Cse, 1, 1), 4, 0.5)).float().requires_grad_(True)
+    b2 = _mk((C,), 5, 0.1).float().requires_grad_(True)
+    a = R.swish(z)
+    sq = F.adaptive_avg_pool2d(a, 1)
+    r = R.swish(F.conv2d(sq, w1, b1))
+    gate = torch.sigmoid(F.conv2d(r, w2, b2))
+    u = gate * a
+    gu = _mk(tuple(u.shape), 6)
+    u.backward(gu)
+    zh, guh = _nhwc(z.detach()), _nhwc(gu)
+    dev = DEV
+    pool = torch.zeros((N, C), device=dev)
+    call('mi355_se_pool', ptr(zh), c_int(1), ptr(pool), c_int(N), c_int(H * W), c_int(C), stream_of(zh))
+    _close(pool, sq.detach().reshape(N, C), 2e-3)
+    rpre = torch.empty((N, Cse), device=dev)
+    g = torch.empty((N, C), device=dev)
+    W1, B1, W2, B2 = [t.detach().to(dev).contiguous() for t in (w1, b1, w2, b2)]
+    call('mi355_se_fc', ptr(pool), ptr(W1), ptr(B1), ptr(W2), ptr(B2), ptr(rpre), ptr(g), c_int(N), c_int(C),
+         c_int(Cse), stream_of(zh))
+    _close(g, gate.detach().reshape(N, C), 2e-3)
+    uh = torch.empty_like(zh)
+    call('mi355_se_scale', ptr(zh), ptr(g), ptr(uh), c_int(N), c_int(H * W), c_int(C), stream_of(zh))
+    _close(uh.permute(0, 3, 1, 2), u.detach(), 1e-2)
+    ggate = torch.zeros((N, C), device=dev)
+    call('mi355_se_bwd_reduce', ptr(guh), ptr(zh), ptr(ggate), c_int(N), c_int(H * W), c_int(C), stream_of(zh))
+    gpool = torch.empty((N, C), device=dev)
+    dW1, dB1, dW2, dB2 = [torch.zeros_like(t) for t in (W1, B1, W2, B2)]
+    call('mi355_se_fc_bwd', ptr(pool), ptr(W1), ptr(W2), ptr(rpre), ptr(g), ptr(ggate), ptr(gpool), ptr(dW1),
+         ptr(dB1), ptr(dW2), ptr(dB2), c_int(N), c_int(C), c_int(Cse), stream_of(zh))
+    gz = torch.empty_like(zh)
+    call('mi355_se_bwd_apply', ptr(guh), ptr(zh), ptr(g), ptr(gpool), ptr(gz), c_int(N), c_int(H * W), c_int(C),
+         stream_of(zh))
+    _close(gz.permute(0, 3, 1, 2), z.grad, 1.5e-2)
+    for got, ref in ((dW1, w1.grad), (dB1, b1.grad), (dW2, w2.grad), (dB2, b2.grad)):
+        _close(got.reshape(ref.shape), ref, 5e-3)
+
+
+def test_bifpn_node_and_fusion_weights():
+    from objectdetection.pytorch_amd._lib import call, ptr, c_int, c_f32, c_i64, stream_of
+    N, C, H, W = 2, 64, 8, 12
+    p = torch.tensor([0.7, -0.2, 1.3], requires_grad=True)
+    a = _mk((N, C, H, W), 1).requires_grad_(True)
+    b = _mk((N, C, H // 2, W // 2), 2).requires_grad_(True)
+    c = _mk((N, C, H, W), 3).requires_grad_(True)
+    w = R.fusion_weights(p)
+    z = w[0] * a + w[1] * F.interpolate(b, scale_factor=2, mode='nearest') + w[2] * c
+    gz = _mk(tuple(z.shape), 4)
+    z.backward(gz)
+    pd = p.detach().to(DEV)
+    wd = torch.empty(3, device=DEV)
+    call('mi355_fusion_weights_fwd', ptr(pd), c_int(3), c_f32(1e-4), ptr(wd), stream_of(pd))
+    _close(wd, w.detach(), 1e-6)
+    ah, bh, ch, gh = _nhwc(a.detach()), _nhwc(b.detach()), _nhwc(c.detach()), _nhwc(gz)
+    zh = torch.empty_like(ah)
+    call('mi355_bifpn_node_fwd', ptr(ah), ptr(bh), c_int(1), ptr(ch), ptr(wd), ptr(zh), c_int(N), c_int(H), c_int(W),
+         c_int(C), stream_of(ah))
+    _close(zh.permute(0, 3, 1, 2), z.detach(), 1e-2)
+    gw = torch.zeros(3, device=DEV)
+    call('mi355_bifpn_node_wgrad', ptr(gh), ptr(ah), ptr(bh), c_int(1), ptr(ch), ptr(gw), c_int(N), c_int(H), c_int(W),
+         c_int(C), stream_of(ah))
+    gp = torch.empty(3, device=DEV)
+    call('mi355_fusion_weights_bwd', ptr(pd), c_int(3), c_f32(1e-4), ptr(gw), ptr(gp), stream_of(pd))
+    _close(gp, p.grad, 5e-3)
+    ga = torch.empty_like(ah)
+    call('mi355_axpy_bf16', ptr(gh), ptr(wd), c_int(0), ptr(ga), c_i64(gh.numel()), c_int(0), stream_of(ah))
+    _close(ga.permute(0, 3, 1, 2), a.grad, 1e-2)
+    gb = torch.zeros_like(bh)
+    call('mi355_upsample_bwd_axpy', ptr(gh), ptr(wd), c_int(1), ptr(gb), c_int(N), c_int(H), c_int(W), c_int(C),
+         c_int(0), stream_of(ah))
+    _close(gb.permute(0, 3, 1, 2), b.grad, 1e-2)
