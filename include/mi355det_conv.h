@@ -81,9 +81,11 @@ int mi355_nchw_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int
 int mi355_prep_weight(const float* w, int64_t sk, int64_t sc, int64_t sr, int64_t ss, int K, int C,
                       int R, int S, int Cpad, const float* scale, void* w_fwd, void* w_dgr,
                       void* stream);
-/* Frozen-BN fold: scale = gamma / sqrt(var + eps), shift = beta - mean * scale  (fp32 [K]). */
+/* Frozen-BN fold: scale = gamma / sqrt(var + eps), shift = beta - (mean - conv_bias) * scale
+ * (fp32 [K]); conv_bias (may be NULL) is the bias of a conv that ALSO feeds the BN
+ * (efficientdet.py:45,52: pointwise conv with bias, then BN). */
 int mi355_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
-                  float eps, int K, float* scale, float* shift, void* stream);
+                  const float* conv_bias, float eps, int K, float* scale, float* shift, void* stream);
 /* Column sums: out[k] (+)= sum_m g[m][k], g bf16 [M][K] (bias / BN-beta gradients). */
 int mi355_colsum_bf16(const void* g, int64_t M, int K, float* out, void* stream);
 /* Finish a conv layer's parameter gradients from the raw wgrad G = X^T dY (fp32 [K][T][Cpad]):
@@ -91,11 +93,14 @@ int mi355_colsum_bf16(const void* g, int64_t M, int K, float* out, void* stream)
  *   if gamma given (frozen BN, retinanet.py:266-270 keeps gamma/beta trainable):
  *     dgamma[k] (+)= invstd[k] * ( sum_{t,c} W[k][c][r][s]*G[k][t][c] - mean[k]*colsum[k] )
  *     dbeta[k]  (+)= colsum[k]
+ *   if the conv has its own bias b in front of the BN: mean -> mean - b in dgamma, and
+ *     dconv_bias[k] (+)= scale[k] * colsum[k]
  * accumulate != 0 adds to the existing gradient buffers. */
 int mi355_conv_param_grads(const float* G, const float* w, int64_t sk, int64_t sc, int64_t sr,
                            int64_t ss, int K, int C, int R, int S, int Cpad, const float* scale,
                            const float* colsum, const float* mean, const float* var, float eps,
-                           float* dW, float* dgamma, float* dbeta, int accumulate, void* stream);
+                           float* dW, float* dgamma, float* dbeta, int accumulate,
+                           const float* conv_bias, float* dconv_bias, void* stream);
 /* MaxPool 3x3 s2 p1 (retinanet.py:188) NHWC bf16; idx int8 [N][P][Q][C] = argmax window slot. */
 int mi355_maxpool3x3s2_fwd(const void* in, void* out, int8_t* idx, int N, int H, int W, int C,
                            void* stream);

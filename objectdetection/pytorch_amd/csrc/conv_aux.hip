@@ -36,20 +36,20 @@ extern "C" int mi355_nchw_to_nhwc_bf16(const float* in, void* out, int N, int C,
 
 // ----------------------------------------------------------------------- frozen-BN fold
 __global__ void bn_fold_kernel(const float* g, const float* b, const float* m, const float* v,
-                               float eps, int K, float* scale, float* shift) {
+                               const float* cb, float eps, int K, float* scale, float* shift) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     const float s = g[k] / sqrtf(v[k] + eps);
     scale[k] = s;
-    shift[k] = b[k] - m[k] * s;
+    shift[k] = b[k] - (m[k] - (cb ? cb[k] : 0.0f)) * s;
 }
 
 extern "C" int mi355_bn_fold(const float* gamma, const float* beta, const float* mean,
-                             const float* var, float eps, int K, float* scale, float* shift,
-                             void* stream) {
+                             const float* var, const float* conv_bias, float eps, int K, float* scale,
+                             float* shift, void* stream) {
     MI355_REQUIRE(gamma && beta && mean && var && scale && shift && K > 0, "bn_fold: bad args");
     hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream,
-                       gamma, beta, mean, var, eps, K, scale, shift);
+                       gamma, beta, mean, var, conv_bias, eps, K, scale, shift);
     return check_launch("bn_fold_kernel");
 }
 
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_param_grads_kernel(
     long long ss, int C, int R, int S, int Cpad, const float* __restrict__ scale,
     const float* __restrict__ colsum, const float* __restrict__ mean, const float* __restrict__ var,
     float eps, float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    int accumulate) {
+    int accumulate, const float* __restrict__ conv_bias, float* __restrict__ dconv_bias) {
     const int k = blockIdx.x, tid = threadIdx.x;
     const int T = R * S;
     const float sck = scale ? scale[k] : 1.0f;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void conv_param_grads_kernel(
         const float d = gv * sck;
         dW[wo] = accumulate ? dW[wo] + d : d;
     }
-    if (dgamma || dbeta) {
+    if (dgamma || dbeta || dconv_bias) {
         __shared__ float red[4];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
@@ -168,10 +168,12 @@ __global__ __launch_bounds__(256) void conv_param_grads_kernel(
             const float cs = colsum[k];
             if (dgamma) {
                 const float invstd = 1.0f / sqrtf(var[k] + eps);
-                const float dg = invstd * ((red[0] + red[1] + red[2] + red[3]) - mean[k] * cs);
+                const float mu = mean[k] - (conv_bias ? conv_bias[k] : 0.0f);
+                const float dg = invstd * ((red[0] + red[1] + red[2] + red[3]) - mu * cs);
                 dgamma[k] = accumulate ? dgamma[k] + dg : dg;
             }
             if (dbeta) dbeta[k] = accumulate ? dbeta[k] + cs : cs;
+            if (dconv_bias) dconv_bias[k] = accumulate ? dconv_bias[k] + sck * cs : sck * cs;
         }
     }
 }
@@ -180,13 +182,14 @@ extern "C" int mi355_conv_param_grads(const float* G, const float* w, int64_t sk
                                       int64_t sr, int64_t ss, int K, int C, int R, int S, int Cpad,
                                       const float* scale, const float* colsum, const float* mean,
                                       const float* var, float eps, float* dW, float* dgamma,
-                                      float* dbeta, int accumulate, void* stream) {
+                                      float* dbeta, int accumulate, const float* conv_bias,
+                                      float* dconv_bias, void* stream) {
     MI355_REQUIRE(G && w && dW && K > 0 && C > 0 && R > 0 && S > 0 && Cpad >= C, "conv_param_grads: bad args");
     MI355_REQUIRE(!(dgamma || dbeta) || colsum, "conv_param_grads: colsum needed for dgamma/dbeta");
     MI355_REQUIRE(!dgamma || (mean && var), "conv_param_grads: mean/var needed for dgamma");
     hipLaunchKernelGGL(conv_param_grads_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, G, w,
                        (long long)sk, (long long)sc, (long long)sr, (long long)ss, C, R, S, Cpad, scale,
-                       colsum, mean, var, eps, dW, dgamma, dbeta, accumulate);
+                       colsum, mean, var, eps, dW, dgamma, dbeta, accumulate, conv_bias, dconv_bias);
     return check_launch("conv_param_grads_kernel");
 }
 

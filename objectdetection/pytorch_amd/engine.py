@@ -30,10 +30,11 @@ def _ceil8(v):
 class LayerSpec(object):
     """One conv (+ optional frozen BN) of the network and its device-side shadows."""
 
-    def __init__(self, name, conv, bn=None):
+    def __init__(self, name, conv, bn=None, tf_same=False):
         self.name, self.conv, self.bn = name, conv, bn
         self.K, self.C, self.R, self.S = conv.weight.shape
         self.stride, self.pad = conv.stride[0], conv.padding[0]
+        self.tf_same = tf_same         # TF "same" padding (utils_extra_efficientnet.py:33-52)
         self.Cpad, self.Kpad = _ceil8(self.C), _ceil8(self.K)
         self.T = self.R * self.S
         self.need_dgrad = True
@@ -46,13 +47,19 @@ class LayerSpec(object):
     def bias_tensor(self):
         return self.shift if self.bn is not None else self.conv.bias
 
+    def geometry(self, H, W):
+        """-> (pad_top, pad_left, P, Q) for an H x W input."""
+        if self.tf_same:
+            P, Q = -(-H // self.stride), -(-W // self.stride)
+            eh = self.stride * (P - 1) + 1 + (self.R - 1) - H
+            ew = self.stride * (Q - 1) + 1 + (self.S - 1) - W
+            return eh // 2, ew // 2, P, Q
+        P, Q = out_hw(H, W, self.R, self.stride, self.pad)[0], out_hw(H, W, self.S, self.stride, self.pad)[1]
+        return self.pad, self.pad, P, Q
+
 
 class RetinaPlan(object):
     def __init__(self, model, B, H, W, device):
-        if H % 32 or W % 32:
-            # the reference's FPN (nn.Upsample x2 + add, retinanet.py:52-61) needs this too;
-            # its Resizer pads to multiples of 32 (datasettool/dataloader.py:887-892)
-            raise ValueError('RetinaNet input must be a multiple of 32, got %dx%d' % (H, W))
         self.model, self.B, self.H, self.W, self.dev = model, B, H, W, device
         self.lib = _lib.lib()
         self.keep = []                 # ctypes objects referenced by the steps
@@ -60,14 +67,22 @@ class RetinaPlan(object):
         self.bufs = []
         self.fwd_launches = []         # (spec, [(n, p, q) per problem]) for FLOP accounting
         self.last_arena = 0
-        self.num_classes = model.classificationModel.num_classes
-        self.A_cell = model.anchors.num_anchors_per_cell
+        self._meta()
+        if H % self.input_multiple or W % self.input_multiple:
+            # the reference's FPN / BiFPN (nn.Upsample x2 + add, retinanet.py:52-61,
+            # efficientdet.py:216) needs this too; its Resizer pads to multiples of 32
+            raise ValueError('input must be a multiple of %d, got %dx%d' % (self.input_multiple, H, W))
         self._collect_layers()
         self._alloc_params()
         self._build_prep()
         self._build_forward()
         self._build_backward()
         self._param_ptrs = self._ptr_signature()
+
+    def _meta(self):
+        self.num_classes = self.model.classificationModel.num_classes
+        self.A_cell = self.model.anchors.num_anchors_per_cell
+        self.input_multiple = 32
 
     # ------------------------------------------------------------------ bookkeeping
     def new(self, shape, dtype=torch.bfloat16, zero=False):
@@ -203,8 +218,8 @@ class RetinaPlan(object):
             if s.bn is not None:
                 bn = s.bn
                 self._step(self.prep_steps, 'mi355_bn_fold', ptr(bn.weight), ptr(bn.bias),
-                           ptr(bn.running_mean), ptr(bn.running_var), c_f32(bn.eps), c_int(s.K),
-                           ptr(s.scale), ptr(s.shift))
+                           ptr(bn.running_mean), ptr(bn.running_var), ptr(s.conv.bias), c_f32(bn.eps),
+                           c_int(s.K), ptr(s.scale), ptr(s.shift))
             sk, sc, sr, ss = w.stride()
             self._step(self.prep_steps, 'mi355_prep_weight', ptr(w), c_i64(sk), c_i64(sc), c_i64(sr),
                        c_i64(ss), c_int(s.K), c_int(s.C), c_int(s.R), c_int(s.S), c_int(s.Cpad),
@@ -235,10 +250,11 @@ class RetinaPlan(object):
     def conv(self, spec, x, act=ACT_NONE, addend=None, add_shift=0):
         N, H, W, C = x.shape
         assert C == spec.Cpad, (spec.name, C, spec.Cpad)
-        P, Q = out_hw(H, W, spec.R, spec.stride, spec.pad)
-        out = self.new((N, P, Q, spec.K))
-        pr = fwd_problem(x, out.data_ptr(), spec.R, spec.S, spec.stride, spec.pad, K=spec.K,
-                         addend=addend, add_shift=add_shift)
+        pt, pl, P, Q = spec.geometry(H, W)
+        out = self.new((N, P, Q, spec.Kpad), zero=spec.Kpad != spec.K)
+        pr = fwd_problem(x, out.data_ptr(), spec.R, spec.S, spec.stride, (pt, pl), K=spec.K,
+                         addend=addend, add_shift=add_shift, out_size=(P, Q),
+                         out_strides=(P * Q * spec.Kpad, Q * spec.Kpad, spec.Kpad))
         self._gather(self.fwd_steps, [pr], spec.w_fwd, spec.K, spec.T, bias=spec.bias_tensor, act=act)
         self.fwd_launches.append((spec, [(N, P, Q)]))
         return out
@@ -246,13 +262,15 @@ class RetinaPlan(object):
     def conv_bwd(self, spec, x, dy, dx=None, addend=None, mask=None, mask_first=False, dgrad=True):
         """wgrad (+ column sums) of `spec` and, optionally, its data gradient into `dx`."""
         N, H, W, C = x.shape
-        pr = fwd_problem(x, dy.data_ptr(), spec.R, spec.S, spec.stride, spec.pad, K=spec.Kpad)
+        pt, pl, P, Q = spec.geometry(H, W)
+        pr = fwd_problem(x, dy.data_ptr(), spec.R, spec.S, spec.stride, (pt, pl), K=spec.Kpad, out_size=(P, Q))
         self._wgrad([pr], spec, N * pr.P * pr.Q)          # + fused column sums (bias / beta grads)
         if not dgrad:
             return None
         if dx is None:
             dx = self.new((N, H, W, spec.Cpad))
-        probs = dgrad_problems(dy, dx.data_ptr(), H, W, spec.Cpad, spec.R, spec.S, spec.stride, spec.pad,
+        assert pt == pl, 'asymmetric-pad dgrad is only needed by the stem, which has no dgrad'
+        probs = dgrad_problems(dy, dx.data_ptr(), H, W, spec.Cpad, spec.R, spec.S, spec.stride, pt,
                                addend=addend, mask=mask)
         self._gather(self.bwd_steps, probs, spec.w_dgr, spec.Cpad, spec.T, flags=1 if mask_first else 0)
         return dx
@@ -486,12 +504,15 @@ class RetinaPlan(object):
             dgam = self.grad_view(bn.weight, arena) if bn is not None else None
             dbet = (self.grad_view(bn.bias, arena) if bn is not None
                     else (self.grad_view(s.conv.bias, arena) if s.conv.bias is not None else None))
+            cb = s.conv.bias if bn is not None else None          # conv bias in front of a BN
+            dcb = self.grad_view(cb, arena) if cb is not None else None
             rc = self.lib.mi355_conv_param_grads(
                 ptr(s.G), ptr(w), c_i64(sk), c_i64(sc), c_i64(sr), c_i64(ss), c_int(s.K), c_int(s.C),
                 c_int(s.R), c_int(s.S), c_int(s.Cpad), ptr(s.scale), ptr(s.colsum),
                 ptr(bn.running_mean if bn is not None else None),
                 ptr(bn.running_var if bn is not None else None),
-                c_f32(bn.eps if bn is not None else 0.0), ptr(dW), ptr(dgam), ptr(dbet), c_int(0), st)
+                c_f32(bn.eps if bn is not None else 0.0), ptr(dW), ptr(dgam), ptr(dbet), c_int(1),   # arena zeroed: += handles shared convs
+                ptr(cb), ptr(dcb), st)
             if rc:
                 raise _lib.Mi355Error('conv_param_grads(%s): %s' % (s.name, self.lib.mi355_last_error().decode()))
 
@@ -533,6 +554,7 @@ class RetinaPlan(object):
         self.glosses[1:2].copy_(g_reg.reshape(1) if g_reg is not None else torch.zeros(1, device=self.dev))
         self.grad_arenas[arena].zero_()
         self.scratch.zero_()
+        self._zero_extra()
         annot = self._annot
         _lib.call('mi355_focal_loss_bwd', ptr(self.cls), ptr(self.reg), ptr(self._anchors), ptr(annot),
                   ptr(self.argmax), ptr(self.state), ptr(self.num_pos), ptr(self.glosses),
@@ -541,7 +563,14 @@ class RetinaPlan(object):
                   c_int(self.A_cell), c_int(self.cls_pitch), c_int(self.reg_pitch), c_vp(st))
         self._run(self.bwd_steps if arena == 0 else self.bwd_steps_alt, st)
         self._run_param_grads(arena, st)
+        self._extra_param_grads(arena, st)
         return [self.grad_view(p, arena) if p.requires_grad else None for p in self.params]
+
+    def _zero_extra(self):
+        pass
+
+    def _extra_param_grads(self, arena, stream):
+        pass
 
     def _arena_for_backward(self):
         lo = self.grad_arenas[0].data_ptr()

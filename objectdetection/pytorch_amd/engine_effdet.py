@@ -1,0 +1,507 @@
+"""Static launch plan for EfficientDet (D0-D5) on the MI355X kernels.
+
+Mirrors architectures/efficientdet.py:528-547 (forward + loss) and its autograd backward:
+EfficientNet MBConv backbone (efficientnet.py:80-115) -> BiFPN fast-attention cells
+(efficientdet.py:195-267) -> separable-conv heads with per-level BN (:335-393) -> fused loss.
+
+Design (the path is HBM-bound): every activation is written ONCE as the
+pre-activation z (bf16); consumers apply swish while loading (depthwise conv, SE pool/scale, BiFPN
+node -> depthwise), so BN, swish, the fusion weights and the SE gate never cost a pass of their own.
+All 1x1 convs (expand / project / pointwise / down-channel) run on the MFMA gather conv with the
+frozen-BN scale folded into the bf16 weights (per pyramid level for the heads' per-level BN).
+
+The backward is emitted from a build-time tape: each forward op registers the launches of its
+backward, replayed in reverse at plan construction; gradient buffers are written by their first
+producer and accumulated (+=) by later ones.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops_conv, ops_detect
+from ._lib import c_f32, c_i64, c_int, c_vp, ptr
+from .engine import LayerSpec, RetinaPlan
+from .ops_conv import ACT_NONE, ACT_SIGMOID, ConvProblem, dgrad_problems, fwd_problem
+from .ops_effdet import same_pad
+
+
+class DwSpec(object):
+    """Depthwise conv (+ optional frozen BN): weights fp32 [C][1][k][k]."""
+
+    def __init__(self, name, conv, bn=None):
+        self.name, self.conv, self.bn = name, conv, bn
+        self.C = conv.weight.shape[0]
+        self.k = conv.weight.shape[2]
+        self.stride = conv.stride[0]
+        self.T = self.k * self.k
+        self.w_t = self.scale = self.shift = self.G_t = self.colsum = None
+
+
+class SeSpec(object):
+    def __init__(self, name, reduce_conv, expand_conv):
+        self.name, self.reduce, self.expand = name, reduce_conv, expand_conv
+        self.Cse, self.C = reduce_conv.weight.shape[0], reduce_conv.weight.shape[1]
+
+
+class EffDetPlan(RetinaPlan):
+    # ------------------------------------------------------------------ meta / layers
+    def _meta(self):
+        self.num_classes = self.model.num_classes
+        self.A_cell = self.model.anchors.num_anchors_per_cell
+        self.input_multiple = 128          # p7 (stride 128) must upsample exactly (efficientdet.py:216)
+
+    def _collect_layers(self):
+        m = self.model
+        self.specs, self.dw_specs, self.se_specs = [], [], []
+
+        def pw(name, wrapped, bn=None, tf_same=False):
+            s = LayerSpec(name, wrapped.conv, bn, tf_same=tf_same)
+            self.specs.append(s)
+            return s
+
+        def dw(name, wrapped, bn=None):
+            s = DwSpec(name, wrapped.conv, bn)
+            self.dw_specs.append(s)
+            return s
+
+        eff = m.backbone_net.model
+        self.stem = pw('stem', eff._conv_stem, eff._bn0, tf_same=True)
+        self.stem.need_dgrad = False
+        self.blocks = []
+        for i, blk in enumerate(eff._blocks):
+            a = blk._block_args
+            rec = {'k': a.kernel_size, 's': a.stride[0] if isinstance(a.stride, (list, tuple)) else a.stride,
+                   'skip': bool(blk.id_skip and (a.stride[0] if isinstance(a.stride, (list, tuple)) else a.stride) == 1
+                                and a.input_filters == a.output_filters)}
+            pre = 'blocks.%d' % i
+            rec['expand'] = pw(pre + '.expand', blk._expand_conv, blk._bn0) if a.expand_ratio != 1 else None
+            rec['dw'] = dw(pre + '.dw', blk._depthwise_conv, blk._bn1)
+            rec['se'] = SeSpec(pre + '.se', blk._se_reduce.conv, blk._se_expand.conv)
+            self.se_specs.append(rec['se'])
+            rec['project'] = pw(pre + '.project', blk._project_conv, blk._bn2)
+            self.blocks.append(rec)
+        self.cells = []
+        for ci, cell in enumerate(m.bifpn):
+            rec = {'mod': cell, 'first': cell.first_time}
+            for nm in ('conv6_up', 'conv5_up', 'conv4_up', 'conv3_up', 'conv4_down', 'conv5_down', 'conv6_down',
+                       'conv7_down'):
+                blk = getattr(cell, nm)
+                rec[nm] = (dw('bifpn.%d.%s.dw' % (ci, nm), blk.depthwise_conv),
+                           pw('bifpn.%d.%s.pw' % (ci, nm), blk.pointwise_conv, blk.bn))
+            if cell.first_time:
+                for nm in ('p5_down_channel', 'p4_down_channel', 'p3_down_channel', 'p5_to_p6', 'p4_down_channel_2',
+                           'p5_down_channel_2'):
+                    seq = getattr(cell, nm)
+                    rec[nm] = pw('bifpn.%d.%s' % (ci, nm), seq[0], seq[1])
+            self.cells.append(rec)
+
+        def head(mod, name):
+            rec = {'dw': [dw('%s.conv_list.%d.dw' % (name, i), mod.conv_list[i].depthwise_conv)
+                          for i in range(mod.num_layers)],
+                   'pw': [[pw('%s.conv_list.%d.pw.l%d' % (name, i, lvl), mod.conv_list[i].pointwise_conv,
+                              mod.bn_list[lvl][i]) for i in range(mod.num_layers)] for lvl in range(5)],
+                   'hdw': dw(name + '.header.dw', mod.header.depthwise_conv),
+                   'hpw': [pw('%s.header.pw.l%d' % (name, lvl), mod.header.pointwise_conv) for lvl in range(5)]}
+            return rec
+
+        self.reg_head = head(m.regressor, 'regressor')
+        self.cls_head = head(m.classifier, 'classifier')
+
+    def _alloc_params(self):
+        super(EffDetPlan, self)._alloc_params()
+        n_w = sum(s.T * s.C for s in self.dw_specs)
+        n_bn = sum(2 * s.C for s in self.dw_specs if s.bn is not None)
+        n_g = sum(s.T * s.C + s.C for s in self.dw_specs)
+        self.dw_wbuf = self.new((n_w + n_bn + 8,), torch.float32)
+        self.dw_scratch = self.new((n_g + 8,), torch.float32, zero=True)
+        wo, go = 0, 0
+        for s in self.dw_specs:
+            s.w_t = self.dw_wbuf[wo:wo + s.T * s.C]
+            wo += s.T * s.C
+            if s.bn is not None:
+                s.scale = self.dw_wbuf[wo:wo + s.C]
+                s.shift = self.dw_wbuf[wo + s.C:wo + 2 * s.C]
+                wo += 2 * s.C
+            s.G_t = self.dw_scratch[go:go + s.T * s.C]
+            s.colsum = self.dw_scratch[go + s.T * s.C:go + s.T * s.C + s.C]
+            go += s.T * s.C + s.C
+
+    # ------------------------------------------------------------------ prep
+    def _build_prep(self):
+        super(EffDetPlan, self)._build_prep()
+        for s in self.dw_specs:
+            if s.bn is not None:
+                bn = s.bn
+                self._step(self.prep_steps, 'mi355_bn_fold', ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+                           ptr(bn.running_var), c_vp(0), c_f32(bn.eps), c_int(s.C), ptr(s.scale), ptr(s.shift))
+            assert s.conv.weight.is_contiguous()
+            self._step(self.prep_steps, 'mi355_dw_prep_weight', ptr(s.conv.weight), ptr(s.scale), c_int(s.C),
+                       c_int(s.k), ptr(s.w_t))
+
+    # ------------------------------------------------------------------ gradient bookkeeping (build time)
+    def grad(self, t):
+        g = self._gbuf.get(id(t))
+        if g is None:
+            g = self.new(tuple(t.shape))
+            self._gbuf[id(t)] = g
+            self.keep.append(t)
+        return g
+
+    def first_write(self, t):
+        """True if nobody wrote grad(t) yet (the caller then overwrites instead of accumulating)."""
+        if id(t) in self._gwritten:
+            return False
+        self._gwritten.add(id(t))
+        return True
+
+    def has_grad(self, t):
+        return id(t) in self._gwritten
+
+    # ------------------------------------------------------------------ ops (forward launch + taped backward)
+    def pw_op(self, spec, x, addend=None):
+        out = self.conv(spec, x, ACT_NONE, addend=addend)
+
+        def bwd():
+            if not self.has_grad(out):
+                return
+            dy = self.grad(out)
+            if addend is not None:                      # residual skip (efficientnet.py:111-114)
+                self._axpy(dy, None, 0, self.grad(addend), not self.first_write(addend))
+            if spec.need_dgrad:
+                dx = self.grad(x)
+                acc = not self.first_write(x)
+                self.conv_bwd(spec, x, dy, dx=dx, addend=dx if acc else None)
+            else:
+                self.conv_bwd(spec, x, dy, dgrad=False)
+        self.tape.append(bwd)
+        return out
+
+    def dw_op(self, spec, x, x_swish):
+        N, H, W, C = x.shape
+        pt, P = same_pad(H, spec.k, spec.stride)
+        pl, Q = same_pad(W, spec.k, spec.stride)
+        out = self.new((N, P, Q, C))
+        geo = (c_int(N), c_int(H), c_int(W), c_int(C), c_int(spec.k), c_int(spec.stride), c_int(pt), c_int(pl),
+               c_int(P), c_int(Q))
+        self._step(self.fwd_steps, 'mi355_dwconv_fwd', ptr(x), c_int(int(x_swish)), ptr(spec.w_t), ptr(spec.shift),
+                   ptr(out), *geo)
+
+        def bwd():
+            if not self.has_grad(out):
+                return
+            dy = self.grad(out)
+            self._step(self.bwd_steps, 'mi355_dwconv_wgrad', ptr(x), c_int(int(x_swish)), ptr(dy), ptr(spec.G_t),
+                       ptr(spec.colsum if spec.bn is not None else None), *geo)
+            dx = self.grad(x)
+            acc = not self.first_write(x)
+            self._step(self.bwd_steps, 'mi355_dwconv_dgrad', ptr(dy), ptr(spec.w_t), ptr(dx),
+                       ptr(x if x_swish else None), *(geo + (c_int(int(acc)),)))
+        self.tape.append(bwd)
+        return out
+
+    def se_op(self, spec, z):
+        N, H, W, C = z.shape
+        HW = H * W
+        pool = self._zero_fwd_alloc(N * C).view(N, C)
+        rpre = self.new((N, spec.Cse), torch.float32)
+        gate = self.new((N, C), torch.float32)
+        u = self.new(tuple(z.shape))
+        w1, b1, w2, b2 = spec.reduce.weight, spec.reduce.bias, spec.expand.weight, spec.expand.bias
+        dims = (c_int(N), c_int(HW), c_int(C))
+        self._step(self.fwd_steps, 'mi355_se_pool', ptr(z), c_int(1), ptr(pool), *dims)
+        self._step(self.fwd_steps, 'mi355_se_fc', ptr(pool), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(rpre), ptr(gate),
+                   c_int(N), c_int(C), c_int(spec.Cse))
+        self._step(self.fwd_steps, 'mi355_se_scale', ptr(z), ptr(gate), ptr(u), *dims)
+
+        def bwd():
+            if not self.has_grad(u):
+                return
+            gu = self.grad(u)
+            ggate = self._zero_bwd_alloc(N * C).view(N, C)
+            gpool = self.new((N, C), torch.float32)
+            self._step(self.bwd_steps, 'mi355_se_bwd_reduce', ptr(gu), ptr(z), ptr(ggate), *dims)
+            self._se_bwd.append((spec, pool, rpre, gate, ggate, gpool, N))
+            self._step(self.bwd_steps, '__se_fc_bwd__', len(self._se_bwd) - 1)
+            gz = self.grad(z)
+            assert self.first_write(z)
+            self._step(self.bwd_steps, 'mi355_se_bwd_apply', ptr(gu), ptr(z), ptr(gate), ptr(gpool), ptr(gz), *dims)
+        self.tape.append(bwd)
+        return u
+
+    def pool_op(self, x):
+        N, H, W, C = x.shape
+        _, P = same_pad(H, 3, 2)
+        _, Q = same_pad(W, 3, 2)
+        out = self.new((N, P, Q, C))
+        idx = self.new((N, P, Q, C), torch.int8)
+        dims = (c_int(N), c_int(H), c_int(W), c_int(C))
+        self._step(self.fwd_steps, 'mi355_maxpool_same_fwd', ptr(x), ptr(out), ptr(idx), *dims)
+
+        def bwd():
+            if not self.has_grad(out):
+                return
+            gx = self.grad(x)
+            acc = not self.first_write(x)
+            self._step(self.bwd_steps, 'mi355_maxpool_same_bwd', ptr(self.grad(out)), ptr(idx), ptr(gx),
+                       *(dims + (c_int(int(acc)),)))
+        self.tape.append(bwd)
+        return out
+
+    def node_op(self, param, in0, in1, up1, in2=None):
+        """z = w0*in0 + w1*in1' (+ w2*in2), w = relu(p)/(sum relu(p) + 1e-4) (efficientdet.py:213-265)."""
+        n = param.numel()
+        w = self.new((4,), torch.float32, zero=True)
+        self._step(self.prep_steps, 'mi355_fusion_weights_fwd', ptr(param), c_int(n), c_f32(1e-4), ptr(w))
+        N, H, W, C = in0.shape
+        z = self.new(tuple(in0.shape))
+        dims = (c_int(N), c_int(H), c_int(W), c_int(C))
+        self._step(self.fwd_steps, 'mi355_bifpn_node_fwd', ptr(in0), ptr(in1), c_int(int(up1)), ptr(in2), ptr(w),
+                   ptr(z), *dims)
+
+        def bwd():
+            if not self.has_grad(z):
+                return
+            gz = self.grad(z)
+            gw = self._zero_bwd_alloc(4)
+            self._step(self.bwd_steps, 'mi355_bifpn_node_wgrad', ptr(gz), ptr(in0), ptr(in1), c_int(int(up1)),
+                       ptr(in2), ptr(gw), *dims)
+            self._fusion_bwd.append((param, n, gw))
+            self._step(self.bwd_steps, '__fusion_bwd__', len(self._fusion_bwd) - 1)
+            self._axpy(gz, w, 0, self.grad(in0), not self.first_write(in0))
+            if up1:
+                self._step(self.bwd_steps, 'mi355_upsample_bwd_axpy', ptr(gz), ptr(w), c_int(1), ptr(self.grad(in1)),
+                           *(dims + (c_int(int(not self.first_write(in1))),)))
+            else:
+                self._axpy(gz, w, 1, self.grad(in1), not self.first_write(in1))
+            if in2 is not None:
+                self._axpy(gz, w, 2, self.grad(in2), not self.first_write(in2))
+        self.tape.append(bwd)
+        return z
+
+    def _axpy(self, src, w, wi, dst, accumulate):
+        self._step(self.bwd_steps, 'mi355_axpy_bf16', ptr(src), ptr(w), c_int(wi), ptr(dst), c_i64(src.numel()),
+                   c_int(int(accumulate)))
+
+    def sep_op(self, pair, z):
+        """SeparableConvBlock on a swish'ed node: dw3x3 (no bias) -> pw 1x1 (+bias) -> BN."""
+        dws, pws = pair
+        return self.pw_op(pws, self.dw_op(dws, z, True))
+
+    # zero-initialised fp32 scratch, carved at build time, cleared once per forward / backward
+    def _zero_fwd_alloc(self, n):
+        t = self._zf[self._zf_off:self._zf_off + n]
+        self._zf_off += (n + 3) // 4 * 4
+        assert self._zf_off <= self._zf.numel()
+        return t
+
+    def _zero_bwd_alloc(self, n):
+        t = self._zb[self._zb_off:self._zb_off + n]
+        self._zb_off += (n + 3) // 4 * 4
+        assert self._zb_off <= self._zb.numel()
+        return t
+
+    # ------------------------------------------------------------------ forward
+    def _build_forward(self):
+        B, H, W = self.B, self.H, self.W
+        m = self.model
+        self._gbuf, self._gwritten, self.tape = {}, set(), []
+        self._se_bwd, self._fusion_bwd = [], []
+        nse = sum(B * s.C for s in self.se_specs)
+        self._zf = self.new((nse + 64,), torch.float32, zero=True)
+        self._zb = self.new((nse + 64 * 8 * len(self.cells) + 64,), torch.float32, zero=True)
+        self._zf_off = self._zb_off = 0
+        self.img_nhwc = self.new((B, H, W, 8))
+        self.dbg = {}
+        cur = self.pw_op(self.stem, self.img_nhwc)          # pre-activation z of the stem (swish on load)
+        self.dbg['stem_z'] = cur
+        cur_sw = True
+        feats, last = [], None
+        nblk = len(self.blocks)
+        for i, rec in enumerate(self.blocks):
+            inp = cur
+            if rec['expand'] is not None:
+                assert not cur_sw
+                dw_in, dw_sw = self.pw_op(rec['expand'], inp), True
+            else:
+                dw_in, dw_sw = inp, cur_sw
+            z1 = self.dw_op(rec['dw'], dw_in, dw_sw)
+            u = self.se_op(rec['se'], z1)
+            cur = self.pw_op(rec['project'], u, addend=inp if rec['skip'] else None)
+            pre = 'backbone_net.model._blocks.%d' % i
+            self.dbg[pre + '.z1'], self.dbg[pre + '.u'], self.dbg['block%d' % i] = z1, u, cur
+            if rec['expand'] is not None:
+                self.dbg[pre + '.z0'] = dw_in
+            cur_sw = False
+            if rec['s'] == 2:                                # efficientdet.py:427-431
+                feats.append(last)
+            elif i == nblk - 1:
+                feats.append(cur)
+            last = cur
+        p3, p4, p5 = feats[2], feats[3], feats[4]
+        fe = (p3, p4, p5)
+        for ci, rec in enumerate(self.cells):
+            fe = self._cell_fwd(rec, fe)
+            for l, f in enumerate(fe):
+                self.dbg['cell%d_p%d' % (ci, l + 3)] = f
+        self.levels = list(fe)
+        self.cells_per_level = [t.shape[1] * t.shape[2] for t in self.levels]
+        self.cell_off = [sum(self.cells_per_level[:i]) for i in range(5)]
+        self.ncells = sum(self.cells_per_level)
+        self.A = self.ncells * self.A_cell
+        C = self.num_classes
+        self.reg = self.new((B, self.A, 4), torch.float32)
+        self.cls = self.new((B, self.A, C), torch.float32)
+        self.cls_pitch = (C * self.A_cell + 7) // 8 * 8
+        self.reg_pitch = (4 * self.A_cell + 7) // 8 * 8
+        self.gcls = self.new((B, self.ncells, self.cls_pitch), zero=True)
+        self.greg = self.new((B, self.ncells, self.reg_pitch), zero=True)
+        self._head_fwd(self.reg_head, self.reg, 4 * self.A_cell, ACT_NONE, self.greg, self.reg_pitch)
+        self._head_fwd(self.cls_head, self.cls, C * self.A_cell, ACT_SIGMOID, self.gcls, self.cls_pitch)
+        # loss state (same fused kernels as RetinaNet)
+        self.losses = self.new((2,), torch.float32)
+        self.argmax = self.new((B, self.A), torch.int32)
+        self.state = self.new((B, self.A), torch.int8)
+        self.num_pos = self.new((B,), torch.int32)
+        nb = ctypes.c_int64()
+        _lib.call('mi355_focal_loss_workspace_bytes', c_int(B), c_int(self.A), c_int(C), c_int(1), ctypes.byref(nb))
+        self.loss_ws = self.new((nb.value,), torch.uint8)
+        self.loss_ws_bytes = nb.value
+        self.glosses = self.new((2,), torch.float32)
+
+    def _cell_fwd(self, rec, inputs):
+        cell = rec['mod']
+        if rec['first']:
+            p3, p4, p5 = inputs
+            p6_in = self.pool_op(self.pw_op(rec['p5_to_p6'], p5))
+            p7_in = self.pool_op(p6_in)
+            p3_in = self.pw_op(rec['p3_down_channel'], p3)
+            p4_in = self.pw_op(rec['p4_down_channel'], p4)
+            p5_in = self.pw_op(rec['p5_down_channel'], p5)
+        else:
+            p3_in, p4_in, p5_in, p6_in, p7_in = inputs
+        p6_up = self.sep_op(rec['conv6_up'], self.node_op(cell.p6_w1, p6_in, p7_in, True))
+        p5_up = self.sep_op(rec['conv5_up'], self.node_op(cell.p5_w1, p5_in, p6_up, True))
+        p4_up = self.sep_op(rec['conv4_up'], self.node_op(cell.p4_w1, p4_in, p5_up, True))
+        p3_out = self.sep_op(rec['conv3_up'], self.node_op(cell.p3_w1, p3_in, p4_up, True))
+        if rec['first']:
+            p4_in = self.pw_op(rec['p4_down_channel_2'], inputs[1])
+            p5_in = self.pw_op(rec['p5_down_channel_2'], inputs[2])
+        p4_out = self.sep_op(rec['conv4_down'], self.node_op(cell.p4_w2, p4_in, p4_up, False, self.pool_op(p3_out)))
+        p5_out = self.sep_op(rec['conv5_down'], self.node_op(cell.p5_w2, p5_in, p5_up, False, self.pool_op(p4_out)))
+        p6_out = self.sep_op(rec['conv6_down'], self.node_op(cell.p6_w2, p6_in, p6_up, False, self.pool_op(p5_out)))
+        p7_out = self.sep_op(rec['conv7_down'], self.node_op(cell.p7_w2, p7_in, self.pool_op(p6_out), False))
+        return p3_out, p4_out, p5_out, p6_out, p7_out
+
+    def _head_fwd(self, rec, out, kout, act, gout, pitch):
+        """efficientdet.py:335-353 / :374-393; the header's pointwise conv writes fp32 straight into
+        the [B, A, .] layout and takes the loss gradient from the padded cell rows of `gout`."""
+        B = self.B
+        per_img = self.ncells * kout
+        for lvl, f in enumerate(self.levels):
+            sw = False
+            for i in range(len(rec['dw'])):
+                f = self.pw_op(rec['pw'][lvl][i], self.dw_op(rec['dw'][i], f, sw))
+                sw = True
+            t = self.dw_op(rec['hdw'], f, True)
+            spec = rec['hpw'][lvl]
+            h, w = t.shape[1], t.shape[2]
+            off = self.cell_off[lvl]
+            pr = fwd_problem(t, out.data_ptr() + 4 * off * kout, 1, 1, 1, 0, out_strides=(per_img, w * kout, kout),
+                             K=kout)
+            self._gather(self.fwd_steps, [pr], spec.w_fwd, kout, 1, bias=spec.conv.bias, act=act, out_f32=True)
+            self.fwd_launches.append((spec, [(B, h, w)]))
+
+            def bwd(t=t, spec=spec, h=h, w=w, off=off):
+                dy_ptr = gout.data_ptr() + 2 * off * pitch
+                wp = fwd_problem(t, dy_ptr, 1, 1, 1, 0, K=pitch)
+                wp.out_sN = self.ncells * pitch
+                self._wgrad([wp], spec, B * h * w)
+                gt = self.grad(t)
+                assert self.first_write(t)
+                dp = ConvProblem()
+                dp.in_, dp.out = dy_ptr, gt.data_ptr()
+                dp.N, dp.H, dp.W, dp.C, dp.P, dp.Q, dp.sh, dp.sw = B, h, w, pitch, h, w, 1, 1
+                dp.TR, dp.TS, dp.dh0, dp.dhs, dp.dw0, dp.dws = 1, 1, 0, -1, 0, -1
+                dp.r0, dp.rs, dp.s0, dp.ss, dp.S = 0, 1, 0, 1, 1
+                dp.out_mh, dp.out_oh, dp.out_mw, dp.out_ow = 1, 0, 1, 0
+                dp.out_sN, dp.out_sH, dp.out_sW = h * w * spec.Cpad, w * spec.Cpad, spec.Cpad
+                dp.in_sN = self.ncells * pitch
+                self._gather(self.bwd_steps, [dp], spec.w_dgr, spec.Cpad, 1)
+            self.tape.append(bwd)
+
+    # ------------------------------------------------------------------ backward
+    def _build_backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self._build_param_grads()
+
+    def _step(self, lst, name, *args):
+        if name.startswith('__'):                     # python-side pseudo steps (tiny per-sample kernels)
+            self.keep.append(args)
+            lst.append((None, args, name))
+            return
+        super(EffDetPlan, self)._step(lst, name, *args)
+
+    def _run(self, steps, stream):
+        s = c_vp(stream)
+        lib = self.lib
+        arena = self.last_arena
+        for fn, args, name in steps:
+            if fn is None:
+                if name == '__se_fc_bwd__':
+                    spec, pool, rpre, gate, ggate, gpool, N = self._se_bwd[args[0]]
+                    rc = lib.mi355_se_fc_bwd(ptr(pool), ptr(spec.reduce.weight), ptr(spec.expand.weight), ptr(rpre),
+                                             ptr(gate), ptr(ggate), ptr(gpool),
+                                             ptr(self.grad_view(spec.reduce.weight, arena)),
+                                             ptr(self.grad_view(spec.reduce.bias, arena)),
+                                             ptr(self.grad_view(spec.expand.weight, arena)),
+                                             ptr(self.grad_view(spec.expand.bias, arena)),
+                                             c_int(N), c_int(spec.C), c_int(spec.Cse), s)
+                else:
+                    param, n, gw = self._fusion_bwd[args[0]]
+                    rc = lib.mi355_fusion_weights_bwd(ptr(param), c_int(n), c_f32(1e-4), ptr(gw),
+                                                      ptr(self.grad_view(param, arena)), s)
+            else:
+                rc = fn(*args, s)
+            if rc:
+                raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, lib.mi355_last_error().decode()))
+
+    def grad_view(self, p, arena):
+        off = self.grad_offsets[id(p)]
+        flat = self.grad_arenas[arena][off:off + p.numel()]
+        if p.dim() == 4 and p.shape[1] > 1 and not p.is_contiguous():
+            return flat.as_strided(p.shape, p.stride())
+        return flat.view(p.shape)
+
+    def _zero_extra(self):
+        self.dw_scratch.zero_()
+        self._zb.zero_()
+
+    def _extra_param_grads(self, arena, stream):
+        st = c_vp(stream)
+        for s in self.dw_specs:
+            bn = s.bn
+            rc = self.lib.mi355_dw_param_grads(
+                ptr(s.G_t), ptr(s.conv.weight), ptr(s.scale), ptr(s.colsum if bn is not None else None),
+                ptr(bn.running_mean if bn is not None else None), ptr(bn.running_var if bn is not None else None),
+                c_f32(bn.eps if bn is not None else 0.0), c_int(s.C), c_int(s.k),
+                ptr(self.grad_view(s.conv.weight, arena)),
+                ptr(self.grad_view(bn.weight, arena) if bn is not None else None),
+                ptr(self.grad_view(bn.bias, arena) if bn is not None else None), c_int(1), st)
+            if rc:
+                raise _lib.Mi355Error('dw_param_grads(%s): %s' % (s.name, self.lib.mi355_last_error().decode()))
+
+    def run_heads(self, img):
+        self._zf.zero_()
+        super(EffDetPlan, self).run_heads(img)
+
+    def _arena_for_backward(self):
+        # gradient accumulation across backward calls without zero_grad is served by autograd
+        # adding the returned views; the EfficientDet plan keeps a single launch list
+        lo = self.grad_arenas[0].data_ptr()
+        hi = lo + self.grad_numel * 4
+        for p in self.params:
+            g = p.grad
+            if g is not None and lo <= g.data_ptr() < hi:
+                p.grad = g.clone()                 # detach live .grad tensors from the arena
+        return 0

@@ -43,15 +43,21 @@ def out_hw(h, w, k, stride, pad):
 
 
 def fwd_problem(x, out_ptr, R, S, stride, pad, out_strides=None, K=None, addend=None, add_shift=0,
-                mask=None):
+                mask=None, out_size=None):
     """Forward-conv problem over NHWC `x`; output NHWC [N,P,Q,K] unless `out_strides`
-    (sN, sH, sW in elements) says otherwise."""
+    (sN, sH, sW in elements) says otherwise.  `pad` may be (pad_top, pad_left) with an explicit
+    `out_size` (TF-"same" asymmetric padding)."""
     N, H, W, C = x.shape
-    P, Q = out_hw(H, W, R, stride, pad)[0], out_hw(H, W, S, stride, pad)[1]
+    if isinstance(pad, tuple):
+        pad_t, pad_l = pad
+        P, Q = out_size
+    else:
+        pad_t = pad_l = pad
+        P, Q = out_hw(H, W, R, stride, pad)[0], out_hw(H, W, S, stride, pad)[1]
     pr = ConvProblem()
     pr.in_, pr.out, pr.addend, pr.mask = x.data_ptr(), out_ptr, _dp(addend), _dp(mask)
     pr.N, pr.H, pr.W, pr.C, pr.P, pr.Q, pr.sh, pr.sw = N, H, W, C, P, Q, stride, stride
-    pr.TR, pr.TS, pr.dh0, pr.dhs, pr.dw0, pr.dws = R, S, -pad, 1, -pad, 1
+    pr.TR, pr.TS, pr.dh0, pr.dhs, pr.dw0, pr.dws = R, S, -pad_t, 1, -pad_l, 1
     pr.r0, pr.rs, pr.s0, pr.ss, pr.S = 0, 1, 0, 1, S
     pr.out_mh, pr.out_oh, pr.out_mw, pr.out_ow = 1, 0, 1, 0
     if out_strides is None:
@@ -184,9 +190,9 @@ def prep_weight(w, cpad, scale, w_fwd, w_dgr):
          c_int(R), c_int(S), c_int(cpad), ptr(scale), ptr(w_fwd), ptr(w_dgr), stream_of(w))
 
 
-def bn_fold(bn, scale, shift):
+def bn_fold(bn, scale, shift, conv_bias=None):
     call('mi355_bn_fold', ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
-         c_f32(bn.eps), c_int(bn.num_features), ptr(scale), ptr(shift), stream_of(scale))
+         ptr(conv_bias), c_f32(bn.eps), c_int(bn.num_features), ptr(scale), ptr(shift), stream_of(scale))
 
 
 def colsum(g, out):
@@ -202,7 +208,7 @@ def conv_param_grads(G, w, cpad, scale, colsum_, bn, dW, dgamma, dbeta, accumula
          c_int(K), c_int(C), c_int(R), c_int(S), c_int(cpad), ptr(scale), ptr(colsum_),
          ptr(bn.running_mean if bn is not None else None),
          ptr(bn.running_var if bn is not None else None), c_f32(bn.eps if bn is not None else 0.0),
-         ptr(dW), ptr(dgamma), ptr(dbeta), c_int(1 if accumulate else 0), stream_of(G))
+         ptr(dW), ptr(dgamma), ptr(dbeta), c_int(1 if accumulate else 0), c_vp(0), c_vp(0), stream_of(G))
 
 
 def maxpool_fwd(x):

@@ -35,6 +35,15 @@ ANCHOR_CFG = dict(pyramid_levels=[3, 4, 5, 6, 7], strides=[8, 16, 32, 64, 128],
                   sizes=[2 ** (x + 1) * 1.25 for x in [3, 4, 5, 6, 7]], ratios=[1, 2])   # :461-468
 
 
+TRACE = None          # set to a dict to capture intermediates (debug aid: tools/debug_effdet.py)
+
+
+def _tr(name, t):
+    if TRACE is not None:
+        TRACE[name] = t.detach()
+    return t
+
+
 def round_filters(filters, width):
     """utils_efficientnet.py:62-74 with depth_divisor 8."""
     filters = filters * width
@@ -91,12 +100,12 @@ def mbconv(x, p, pre, k, s, e, cin, cout):
     """efficientnet.py:80-115 (drop-connect off)."""
     inp = x
     if e != 1:
-        x = swish(bn(conv_same(x, p[pre + '._expand_conv.conv.weight']), p, pre + '._bn0'))
-    x = swish(bn(conv_same(x, p[pre + '._depthwise_conv.conv.weight'], None, s, x.shape[1]), p, pre + '._bn1'))
+        x = swish(_tr(pre + '.z0', bn(conv_same(x, p[pre + '._expand_conv.conv.weight']), p, pre + '._bn0')))
+    x = swish(_tr(pre + '.z1', bn(conv_same(x, p[pre + '._depthwise_conv.conv.weight'], None, s, x.shape[1]), p, pre + '._bn1')))
     sq = F.adaptive_avg_pool2d(x, 1)
     sq = swish(F.conv2d(sq, p[pre + '._se_reduce.conv.weight'], p[pre + '._se_reduce.conv.bias']))
     sq = F.conv2d(sq, p[pre + '._se_expand.conv.weight'], p[pre + '._se_expand.conv.bias'])
-    x = torch.sigmoid(sq) * x
+    x = _tr(pre + '.u', torch.sigmoid(sq) * x)
     x = bn(conv_same(x, p[pre + '._project_conv.conv.weight']), p, pre + '._bn2')
     if s == 1 and cin == cout:
         x = x + inp
@@ -107,10 +116,10 @@ def backbone(p, img, compound_coef):
     """efficientdet.py:411-433: returns (p3, p4, p5) = feature_maps[1:] minus P2 (:533)."""
     _, blocks = block_table(compound_coef)
     pre = 'backbone_net.model.'
-    x = swish(bn(conv_same(img, p[pre + '_conv_stem.conv.weight'], None, 2), p, pre + '_bn0'))
+    x = swish(_tr('stem_z', bn(conv_same(img, p[pre + '_conv_stem.conv.weight'], None, 2), p, pre + '_bn0')))
     feats, last = [], None
     for i, (k, s, e, ci, co) in enumerate(blocks):
-        x = mbconv(x, p, pre + '_blocks.%d' % i, k, s, e, ci, co)
+        x = _tr('block%d' % i, mbconv(x, p, pre + '_blocks.%d' % i, k, s, e, ci, co))
         if s == 2:
             feats.append(last)
         elif i == len(blocks) - 1:
@@ -186,6 +195,8 @@ def efficientdet_heads(p, img, compound_coef, num_classes):
     feats = backbone(p, img, compound_coef)
     for c in range(FPN_REPEATS[compound_coef]):
         feats = bifpn_cell(p, 'bifpn.%d.' % c, feats, c == 0)
+        for l, f in enumerate(feats):
+            _tr('cell%d_p%d' % (c, l + 3), f)
     n = BOX_CLASS_REPEATS[compound_coef]
     reg = head(p, 'regressor', feats, n, 4)
     cls = torch.sigmoid(head(p, 'classifier', feats, n, num_classes))

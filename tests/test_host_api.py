@@ -71,3 +71,19 @@ def test_no_cpu_fallback():
 def test_oracle_state_shapes_helper():
     s = ref_cpu.retinanet_state_shapes(50, 80)
     assert len(s) == 354
+
+
+@pytest.mark.parametrize('tag,coef', [('effdet_d0_128', 0), ('effdet_d2_128x256', 2)])
+def test_efficientdet_state_dict_matches_reference(golden_dir, tag, coef):
+    from objectdetection.pytorch_amd.architectures import efficientdet
+    g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
+    model = efficientdet.build_efficientdet('efficientdet-d%d' % coef, num_classes=int(g['num_classes']))
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g['state_keys']]           # 784 (D0) / 1076 (D2) entries
+    assert [','.join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g['state_shapes']]
+    assert model.anchors.num_anchors_per_cell == 6 and list(model.anchors.ratios) == [1, 2]
+    assert all(not m.training for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 128, 128), torch.zeros(1, 1, 5))          # no CPU fallback
+    with pytest.raises(RuntimeError):
+        efficientdet.EfficientDet(num_classes=3, compound_coef=0, load_weights=True)   # never fetch
