@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--depth', type=int, default=50)
+    ap.add_argument('--arch', default='retinanet', help="'retinanet' (headline) or 'efficientdet-dN' (configs[3], [4])")
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -52,13 +53,19 @@ def parse():
     return ap.parse_args()
 
 
-def build_model(depth, num_classes, dev):
-    from objectdetection.pytorch_amd.architectures import retinanet
-    model = retinanet.retinanet(depth, num_classes=num_classes)
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    # deterministic non-degenerate weights (random frozen-BN statistics, head outputs in a useful
-    # range: see tests/synth.py) - random-init weights of the named architecture
-    sd = synth.synth_state_dict(shapes, seed=0, gain=0.78 if depth >= 50 else 0.87)
+def build_model(depth, num_classes, dev, arch='retinanet'):
+    if arch.startswith('efficientdet'):
+        from objectdetection.pytorch_amd.architectures import efficientdet
+        model = efficientdet.build_efficientdet(arch, num_classes=num_classes)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        sd = synth.synth_state_dict(shapes, seed=0, gain=1.0, head_std=0.05)
+    else:
+        from objectdetection.pytorch_amd.architectures import retinanet
+        model = retinanet.retinanet(depth, num_classes=num_classes)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        # deterministic non-degenerate weights (random frozen-BN statistics, head outputs in a useful
+        # range: see tests/synth.py) - random-init weights of the named architecture
+        sd = synth.synth_state_dict(shapes, seed=0, gain=0.78 if depth >= 50 else 0.87)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.to(dev)
     model.train()
@@ -156,7 +163,8 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
     num_classes = 80
-    model, sd = build_model(args.depth, num_classes, dev)
+    model, sd = build_model(args.depth, num_classes, dev, args.arch)
+    name = 'RetinaNet-R%d' % args.depth if args.arch == 'retinanet' else 'EfficientDet-D' + args.arch[-1]
     B, S = args.batch, args.size
     # each rank owns its shard of the global batch (weak scaling: per-GPU batch fixed)
     img = torch.from_numpy(synth.synth_images(B, S, S, seed=100 + rank)).to(dev)
@@ -206,13 +214,13 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
     out = {
-        'metric': 'images/sec training (RetinaNet-R%d, %dx%d, bs=%d/GPU)' % (args.depth, S, S, B),
+        'metric': 'images/sec training (%s, %dx%d, bs=%d/GPU)' % (name, S, S, B),
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'RetinaNet-R%d FPN, %dx%d, bf16 MFMA convs (fp32 accumulate, fp32 loss '
+        'config': {'workload': '%s, %dx%d, bf16 MFMA convs (fp32 accumulate, fp32 loss '
                                'and optimizer), batch=%d/GPU, fwd+FocalLoss+bwd+clip+AdamW, frozen BN'
-                               % (args.depth, S, S, B),
+                               % (name, S, S, B),
                    'global_batch': world * B, 'parallelism': 'dp%d' % world,
                    'final_loss': [round(float(v), 5) for v in (loss_acc / (args.warmup + args.steps)).tolist()]},
     }
@@ -226,7 +234,7 @@ def main():
                            'kernel': 'conv_gather_kernel + conv_wgrad_kernel (%d launches/step)' % nlaunch,
                            'algorithmic_gflop_per_image': round(train_f / B / 1e9, 2),
                            'conv_ms_per_step': round(conv_ms, 3)}
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and args.arch == 'retinanet':
         out['cpu_baseline'] = cpu_baseline(args.depth, S, sd, num_classes)
     if rank == 0:
         print(json.dumps(out))
