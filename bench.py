@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--graph', type=int, default=int(os.environ.get('MI355_GRAPH', '1')),
+                    help='replay the step from captured hipGraphs (default on)')
     ap.add_argument('--torch-optim', action='store_true',
                     help='autograd + torch clip/AdamW instead of the flat HIP optimizer')
     return ap.parse_args()
@@ -188,7 +190,8 @@ def main():
             loss_acc.add_(torch.cat([cl.detach(), rl.detach()]))
     else:
         from objectdetection.pytorch_amd.trainer import Trainer
-        trainer = Trainer(model, lr=1e-4, weight_decay=5e-4, clip_norm=0.1)   # train.py:259-260, 320
+        trainer = Trainer(model, lr=1e-4, weight_decay=5e-4, clip_norm=0.1,   # train.py:259-260, 320
+                          graph=bool(args.graph), max_annots=ann.shape[1])
 
         def step():
             loss_acc.add_(trainer.step(img, ann))                 # fwd+loss+bwd+allreduce+clip+AdamW
@@ -222,6 +225,7 @@ def main():
                                'and optimizer), batch=%d/GPU, fwd+FocalLoss+bwd+clip+AdamW, frozen BN'
                                % (name, S, S, B),
                    'global_batch': world * B, 'parallelism': 'dp%d' % world,
+                   'launch': 'hipGraph replay' if (args.graph and not args.torch_optim) else 'eager',
                    'final_loss': [round(float(v), 5) for v in (loss_acc / (args.warmup + args.steps)).tolist()]},
     }
     plan = model._plans[next(iter(model._plans))]

@@ -16,8 +16,14 @@ from ._lib import c_f32, c_i64, c_int, c_vp, ptr
 
 class Trainer(object):
     def __init__(self, model, lr=1e-4, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8,
-                 clip_norm=0.1, group=None, bucket_bytes=0):
+                 clip_norm=0.1, group=None, bucket_bytes=0, graph=False, max_annots=128):
+        """graph=True replays the step from two captured hipGraphs (forward+loss+backward | clip+AdamW;
+        the RCCL all-reduce stays between them on the stream): ~400-2000 launches cost one graph
+        launch each.  Inputs are copied into static buffers; annotations are padded with -1 rows
+        to `max_annots` (pad rows are ignored exactly, losses.py:50)."""
         self.model, self.group, self.bucket_bytes = model, group, bucket_bytes
+        self.use_graph, self.max_annots = graph, max_annots
+        self._graphs = None
         self.lr, self.wd, self.betas, self.eps, self.clip_norm = lr, weight_decay, betas, eps, clip_norm
         self.lib = _lib.lib()
         self._flatten()
@@ -50,27 +56,79 @@ class Trainer(object):
         return int(self.state[0].item())
 
     def step(self, img, annot):
+        if self.use_graph:
+            return self._step_graph(img, annot)
+        plan, losses = self._fwd_bwd(img, annot)
+        self._exchange_and_update(plan, losses)
+        return losses
+
+    def _fwd_bwd(self, img, annot):
         model = self.model
         plan = model._plan(img)
         anchors = model.anchors(img)
-        st = torch.cuda.current_stream(img.device).cuda_stream
         plan.run_heads(img)
         losses = plan.run_loss(anchors, annot)
         # loss = cls.mean() + reg.mean() (train.py:312-314): upstream gradient 1 for both
         plan.run_backward(self.ones[0:1], self.ones[1:2])
+        return plan, losses
+
+    def _exchange(self, plan, losses):
         grad = plan.grad_arenas[plan.last_arena]
         dp.allreduce_mean_(grad, self.group, self.bucket_bytes)
-        loss_flag = losses
         if dp.world(self.group)[1] > 1:
-            loss_flag = dp.reduce_losses_(losses.clone(), self.group)
-        s = c_vp(st)
+            return dp.reduce_losses_(losses.clone(), self.group)
+        return losses
+
+    def _exchange_and_update(self, plan, losses):
+        self._update(plan, self._exchange(plan, losses))
+
+    def _step_graph(self, img, annot):
+        dev = img.device
+        if self._graphs is None:
+            B, M = img.shape[0], annot.shape[1]
+            if M > self.max_annots:
+                raise ValueError('annotations per image %d > max_annots %d' % (M, self.max_annots))
+            self._s_img = torch.empty_like(img, dtype=torch.float32).contiguous()
+            self._s_ann = -torch.ones((B, self.max_annots, 5), dtype=torch.float32, device=dev)
+            self._s_flag = torch.zeros(2, dtype=torch.float32, device=dev)
+        if annot.shape[1] > self.max_annots or tuple(img.shape) != tuple(self._s_img.shape):
+            raise ValueError('graph mode needs a fixed image shape and <= max_annots annotations')
+        self._s_img.copy_(img)
+        self._s_ann.fill_(-1.0)
+        self._s_ann[:, :annot.shape[1]].copy_(annot)
+        if self._graphs is None:
+            # warm-up on a side stream (plan build, hipFuncSetAttribute, allocator), then capture
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                plan, losses = self._fwd_bwd(self._s_img, self._s_ann)
+                self._update(plan, self._exchange(plan, losses))
+                first = losses.clone()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                plan, losses = self._fwd_bwd(self._s_img, self._s_ann)
+            self._g_plan, self._g_losses = plan, losses
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._update(plan, self._s_flag)
+            self._graphs = (g1, g2)
+            return first                           # this step already ran eagerly (the warm-up)
+        g1, g2 = self._graphs
+        g1.replay()
+        self._s_flag.copy_(self._exchange(self._g_plan, self._g_losses))
+        g2.replay()
+        return self._g_losses
+
+    def _update(self, plan, loss_flag):
+        grad = plan.grad_arenas[plan.last_arena]
+        s = c_vp(torch.cuda.current_stream(grad.device).cuda_stream)
         self._call('mi355_grad_sumsq', ptr(grad), c_i64(plan.grad_numel_padded), ptr(self.partials), s)
         self._call('mi355_adamw_prepare', ptr(self.partials), ptr(loss_flag), c_f32(self.clip_norm),
                    ptr(self.state), s)
         self._call('mi355_adamw_flat', ptr(self.flat), ptr(grad), ptr(self.m), ptr(self.v),
                    c_i64(self.npad), c_f32(self.lr), c_f32(self.betas[0]), c_f32(self.betas[1]),
                    c_f32(self.eps), c_f32(self.wd), ptr(self.state), c_int(1), s)
-        return losses
 
     def _call(self, name, *args):
         rc = getattr(self.lib, name)(*args)
