@@ -35,6 +35,8 @@ int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, const void* z
 int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, float* dw_t, float* colsum, int N,
                        int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
                        void* stream);
+/* a = swish(z) elementwise (n elements, multiple of 8): materialised input for dwconv_wgrad */
+int mi355_swish_bf16(const void* z, void* a, int64_t n, void* stream);
 /* finish depthwise parameter grads: dW[c][k][k] (+)= G_t[t][c]*scale[c]; frozen-BN dgamma/dbeta
  * (gamma may be NULL: plain conv). */
 int mi355_dw_param_grads(const float* G_t, const float* w, const float* scale, const float* colsum,

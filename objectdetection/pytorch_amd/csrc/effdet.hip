@@ -152,7 +152,8 @@ extern "C" int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, co
     return check_launch("dwconv_dgrad_kernel");
 }
 
-// thread = (tap, 8-channel chunk); block.y = pixel chunk.  8 accumulators per thread.
+// thread = (tap, 8-channel chunk); block.y = a chunk of output rows (n, p).  8 accumulators per
+// thread; the row loop is unrolled by 4 pixels so that 8 loads are in flight per thread.
 template <bool SWISH>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(
     const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy, float* __restrict__ dw_t,
@@ -163,30 +164,52 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(
     if (item >= T * c8n) return;
     const int tap = item / c8n, c8 = item - tap * c8n;
     const int a = tap / k, b = tap - a * k;
-    const long long M = (long long)N * P * Q;
-    const long long m0 = (long long)blockIdx.y * rows_per_block;
-    const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    const int nrows = N * P;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(nrows, r0 + rows_per_block);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long long m = m0; m < m1; ++m) {
-        const int q = (int)(m % Q);
-        const long long r = m / Q;
-        const int p = (int)(r % P), n = (int)(r / P);
-        float g[8];
-        load8(dy + m * C + c8 * 8, g);
-        if (colsum && tap == 0) {
+    const bool do_cs = colsum != nullptr && tap == 0;
+    // valid q range for this tap: 0 <= q*stride - pad_l + b < W
+    const int qlo = max(0, (pad_l - b + stride - 1) / stride);
+    const int qhi = min(Q, (W - 1 + pad_l - b) / stride + 1);
+    for (int r = r0; r < r1; ++r) {
+        const int n = r / P, p = r - n * P;
+        const unsigned short* dyr = dy + (long long)r * Q * C + c8 * 8;
+        if (do_cs) {
+            for (int q = 0; q < Q; ++q) {
+                float g[8];
+                load8(dyr + (long long)q * C, g);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) cs[e] += g[e];
+                for (int e = 0; e < 8; ++e) cs[e] += g[e];
+            }
         }
-        const int h = p * stride - pad_t + a, w = q * stride - pad_l + b;
-        if ((unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) continue;
-        float v[8];
-        load8(x + (((long long)n * H + h) * W + w) * C + c8 * 8, v);
+        const int h = p * stride - pad_t + a;
+        if ((unsigned)h >= (unsigned)H) continue;
+        const unsigned short* xr = x + ((long long)n * H + h) * W * C + c8 * 8 + (long long)(b - pad_l) * C;
+        int q = qlo;
+        for (; q + 4 <= qhi; q += 4) {
+            float g[4][8], v[4][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += (SWISH ? swishf(v[e]) : v[e]) * g[e];
+            for (int u = 0; u < 4; ++u) {
+                load8(dyr + (long long)(q + u) * C, g[u]);
+                load8(xr + (long long)(q + u) * stride * C, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (SWISH ? swishf(v[u][e]) : v[u][e]) * g[u][e];
+        }
+        for (; q < qhi; ++q) {
+            float g[8], v[8];
+            load8(dyr + (long long)q * C, g);
+            load8(xr + (long long)q * stride * C, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (SWISH ? swishf(v[e]) : v[e]) * g[e];
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) atomicAdd(dw_t + tap * C + c8 * 8 + e, acc[e]);
-    if (colsum && tap == 0) {
+    if (do_cs) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) atomicAdd(colsum + c8 * 8 + e, cs[e]);
     }
@@ -196,25 +219,43 @@ extern "C" int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, f
                                   int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
                                   void* stream) {
     MI355_REQUIRE(x && dy && dw_t && N > 0 && C > 0 && C % 8 == 0 && k > 0, "dwconv_wgrad: bad args");
-    const long long M = (long long)N * P * Q;
+    const int nrows = N * P;
     const int items = k * k * (C / 8);
     const int bx = (items + 255) / 256;
-    long long chunks = 2048 / bx;                         // ~2048 blocks in flight
+    int chunks = 4096 / bx;                               // ~4096 blocks
     if (chunks < 1) chunks = 1;
-    long long rows = (M + chunks - 1) / chunks;
-    if (rows < 32) rows = 32;
-    const long long by = (M + rows - 1) / rows;
+    int rows = (nrows + chunks - 1) / chunks;
+    if (rows < 1) rows = 1;
+    const int by = (nrows + rows - 1) / rows;
     MI355_REQUIRE(by <= 65535, "dwconv_wgrad: grid");
     dim3 grid((unsigned)bx, (unsigned)by);
     if (in_swish)
         hipLaunchKernelGGL(dwconv_wgrad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const unsigned short*)x, (const unsigned short*)dy, dw_t, colsum, N, H, W, C, k, stride,
-                           pad_t, pad_l, P, Q, (int)rows);
+                           pad_t, pad_l, P, Q, rows);
     else
         hipLaunchKernelGGL(dwconv_wgrad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const unsigned short*)x, (const unsigned short*)dy, dw_t, colsum, N, H, W, C, k, stride,
-                           pad_t, pad_l, P, Q, (int)rows);
+                           pad_t, pad_l, P, Q, rows);
     return check_launch("dwconv_wgrad_kernel");
+}
+
+// a = swish(z), materialised once when several taps would otherwise recompute it (dw wgrad)
+__global__ void swish_bf16_kernel(const unsigned short* __restrict__ z, unsigned short* __restrict__ a, long long n8) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n8) return;
+    float v[8];
+    load8(z + t * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = swishf(v[e]);
+    store8(a + t * 8, v);
+}
+
+extern "C" int mi355_swish_bf16(const void* z, void* a, int64_t n, void* stream) {
+    MI355_REQUIRE(z && a && n > 0 && n % 8 == 0, "swish_bf16: n must be a multiple of 8");
+    hipLaunchKernelGGL(swish_bf16_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)z, (unsigned short*)a, (long long)(n / 8));
+    return check_launch("swish_bf16_kernel");
 }
 
 __global__ void dw_param_grads_kernel(const float* __restrict__ G_t, const float* __restrict__ w,
@@ -302,7 +343,8 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const unsigned short* __
 }
 
 static void se_grid(int N, int HW, int* rows, dim3* grid) {
-    int slabs = (HW + 2047) / 2048;
+    int slabs = (2048 + N - 1) / N;                      // ~2048 blocks in total
+    if (slabs > (HW + 63) / 64) slabs = (HW + 63) / 64;  // >= 64 rows per block
     if (slabs < 1) slabs = 1;
     *rows = (HW + slabs - 1) / slabs;
     *grid = dim3((unsigned)slabs, (unsigned)N);

@@ -190,7 +190,12 @@ class EffDetPlan(RetinaPlan):
             if not self.has_grad(out):
                 return
             dy = self.grad(out)
-            self._step(self.bwd_steps, 'mi355_dwconv_wgrad', ptr(x), c_int(int(x_swish)), ptr(dy), ptr(spec.G_t),
+            xw, xw_sw = x, x_swish
+            if x_swish:                                 # swish once, not once per tap
+                xw = self._swish_tmp(x.numel()).view(x.shape)
+                self._step(self.bwd_steps, 'mi355_swish_bf16', ptr(x), ptr(xw), c_i64(x.numel()))
+                xw_sw = False
+            self._step(self.bwd_steps, 'mi355_dwconv_wgrad', ptr(xw), c_int(int(xw_sw)), ptr(dy), ptr(spec.G_t),
                        ptr(spec.colsum if spec.bn is not None else None), *geo)
             dx = self.grad(x)
             acc = not self.first_write(x)
@@ -277,6 +282,12 @@ class EffDetPlan(RetinaPlan):
                 self._axpy(gz, w, 2, self.grad(in2), not self.first_write(in2))
         self.tape.append(bwd)
         return z
+
+    def _swish_tmp(self, n):
+        """One shared scratch tensor (launches are stream-ordered) for materialised swish(z)."""
+        if getattr(self, '_swish_buf', None) is None or self._swish_buf.numel() < n:
+            self._swish_buf = self.new((n,))
+        return self._swish_buf[:n]
 
     def _axpy(self, src, w, wi, dst, accumulate):
         self._step(self.bwd_steps, 'mi355_axpy_bf16', ptr(src), ptr(w), c_int(wi), ptr(dst), c_i64(src.numel()),
