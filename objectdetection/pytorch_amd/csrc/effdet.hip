@@ -152,66 +152,90 @@ extern "C" int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, co
     return check_launch("dwconv_dgrad_kernel");
 }
 
-// thread = (tap, 8-channel chunk); block.y = a chunk of output rows (n, p).  8 accumulators per
-// thread; the row loop is unrolled by 4 pixels so that 8 loads are in flight per thread.
+// block = 32 (tap, 8-channel chunk) items x 8 pixel lanes over a chunk of output rows; the pixel
+// lanes are reduced through LDS so that a block issues ONE atomic per (tap, channel): contention on
+// the tiny dw_t tensor is the number of row chunks (~100), not the number of threads.
+constexpr int DW_IPB = 32, DW_PL = 8;
 template <bool SWISH>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(
     const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy, float* __restrict__ dw_t,
     float* __restrict__ colsum, int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
     int rows_per_block) {
+    __shared__ float s_acc[DW_PL][DW_IPB][9];
     const int c8n = C >> 3, T = k * k;
-    const int item = blockIdx.x * 256 + threadIdx.x;           // (tap, c8)
-    if (item >= T * c8n) return;
-    const int tap = item / c8n, c8 = item - tap * c8n;
+    const int il = threadIdx.x % DW_IPB, pl = threadIdx.x / DW_IPB;
+    const int item = blockIdx.x * DW_IPB + il;                 // (tap, c8)
+    const bool live = item < T * c8n;
+    const int tap = live ? item / c8n : 0, c8 = live ? item - tap * c8n : 0;
     const int a = tap / k, b = tap - a * k;
     const int nrows = N * P;
     const int r0 = blockIdx.y * rows_per_block;
     const int r1 = min(nrows, r0 + rows_per_block);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool do_cs = colsum != nullptr && tap == 0;
-    // valid q range for this tap: 0 <= q*stride - pad_l + b < W
+    const bool do_cs = colsum != nullptr && tap == 0 && live;
     const int qlo = max(0, (pad_l - b + stride - 1) / stride);
     const int qhi = min(Q, (W - 1 + pad_l - b) / stride + 1);
-    for (int r = r0; r < r1; ++r) {
-        const int n = r / P, p = r - n * P;
-        const unsigned short* dyr = dy + (long long)r * Q * C + c8 * 8;
-        if (do_cs) {
-            for (int q = 0; q < Q; ++q) {
-                float g[8];
+    if (live) {
+        for (int r = r0; r < r1; ++r) {
+            const int n = r / P, p = r - n * P;
+            const unsigned short* dyr = dy + (long long)r * Q * C + c8 * 8;
+            if (do_cs) {
+                for (int q = pl; q < Q; q += DW_PL) {
+                    float g[8];
+                    load8(dyr + (long long)q * C, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cs[e] += g[e];
+                }
+            }
+            const int h = p * stride - pad_t + a;
+            if ((unsigned)h >= (unsigned)H) continue;
+            const unsigned short* xr = x + ((long long)n * H + h) * W * C + c8 * 8 + (long long)(b - pad_l) * C;
+            int q = qlo + pl;
+            for (; q + DW_PL < qhi; q += 2 * DW_PL) {
+                float g0[8], v0[8], g1[8], v1[8];
+                load8(dyr + (long long)q * C, g0);
+                load8(xr + (long long)q * stride * C, v0);
+                load8(dyr + (long long)(q + DW_PL) * C, g1);
+                load8(xr + (long long)(q + DW_PL) * stride * C, v1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    acc[e] += (SWISH ? swishf(v0[e]) : v0[e]) * g0[e] + (SWISH ? swishf(v1[e]) : v1[e]) * g1[e];
+            }
+            for (; q < qhi; q += DW_PL) {
+                float g[8], v[8];
                 load8(dyr + (long long)q * C, g);
+                load8(xr + (long long)q * stride * C, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) cs[e] += g[e];
+                for (int e = 0; e < 8; ++e) acc[e] += (SWISH ? swishf(v[e]) : v[e]) * g[e];
             }
-        }
-        const int h = p * stride - pad_t + a;
-        if ((unsigned)h >= (unsigned)H) continue;
-        const unsigned short* xr = x + ((long long)n * H + h) * W * C + c8 * 8 + (long long)(b - pad_l) * C;
-        int q = qlo;
-        for (; q + 4 <= qhi; q += 4) {
-            float g[4][8], v[4][8];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                load8(dyr + (long long)(q + u) * C, g[u]);
-                load8(xr + (long long)(q + u) * stride * C, v[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += (SWISH ? swishf(v[u][e]) : v[u][e]) * g[u][e];
-        }
-        for (; q < qhi; ++q) {
-            float g[8], v[8];
-            load8(dyr + (long long)q * C, g);
-            load8(xr + (long long)q * stride * C, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += (SWISH ? swishf(v[e]) : v[e]) * g[e];
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(dw_t + tap * C + c8 * 8 + e, acc[e]);
-    if (do_cs) {
+    for (int e = 0; e < 8; ++e) s_acc[pl][il][e] = acc[e];
+    __syncthreads();
+    if (pl == 0 && live) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(colsum + c8 * 8 + e, cs[e]);
+        for (int e = 0; e < 8; ++e) {
+            float t = 0.0f;
+#pragma unroll
+            for (int l = 0; l < DW_PL; ++l) t += s_acc[l][il][e];
+            atomicAdd(dw_t + tap * C + c8 * 8 + e, t);
+        }
+    }
+    if (colsum) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_acc[pl][il][e] = cs[e];
+        __syncthreads();
+        if (pl == 0 && do_cs) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = 0.0f;
+#pragma unroll
+                for (int l = 0; l < DW_PL; ++l) t += s_acc[l][il][e];
+                atomicAdd(colsum + c8 * 8 + e, t);
+            }
+        }
     }
 }
 
@@ -221,13 +245,13 @@ extern "C" int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, f
     MI355_REQUIRE(x && dy && dw_t && N > 0 && C > 0 && C % 8 == 0 && k > 0, "dwconv_wgrad: bad args");
     const int nrows = N * P;
     const int items = k * k * (C / 8);
-    const int bx = (items + 255) / 256;
-    int chunks = 4096 / bx;                               // ~4096 blocks
+    const int bx = (items + DW_IPB - 1) / DW_IPB;
+    int chunks = 2048 / bx;                               // ~2048 blocks, <= 128-way atomic contention
+    if (chunks > 128) chunks = 128;
     if (chunks < 1) chunks = 1;
     int rows = (nrows + chunks - 1) / chunks;
     if (rows < 1) rows = 1;
     const int by = (nrows + rows - 1) / rows;
-    MI355_REQUIRE(by <= 65535, "dwconv_wgrad: grid");
     dim3 grid((unsigned)bx, (unsigned)by);
     if (in_swish)
         hipLaunchKernelGGL(dwconv_wgrad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
