@@ -108,7 +108,7 @@ def conv_flops(plan):
 def time_conv_kernels(plan, iters):
     """HIP-event time of ONLY the MFMA conv launches of one step (forward gather convs,
     backward gather convs = dgrad, wgrad), replayed back-to-back on the launch stream."""
-    names = ('mi355_conv_gather', 'mi355_conv_wgrad', 'mi355_conv_wgrad_colsum')
+    names = ('mi355_conv_gather', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_slabs', 'mi355_slab_reduce')
     steps = [s for s in plan.fwd_steps + plan.bwd_steps if s[2] in names]
     st = torch.cuda.current_stream()
     plan.grad_arenas[0].zero_()
@@ -160,10 +160,16 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     assert torch.cuda.is_available(), 'bench.py needs a ROCm GPU (no CPU fallback in the product path)'
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(ndev, 1)        # (rehearsals with more ranks than GPUs share a device)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('MI355_DIST_BACKEND', 'nccl')   # 'nccl' == RCCL over xGMI on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     num_classes = 80
     model, sd = build_model(args.depth, num_classes, dev, args.arch)
     name = 'RetinaNet-R%d' % args.depth if args.arch == 'retinanet' else 'EfficientDet-D' + args.arch[-1]

@@ -70,6 +70,17 @@ int mi355_conv_wgrad(const Mi355ConvLaunch* launch, float* dw, int split_rows, v
 int mi355_conv_wgrad_colsum(const Mi355ConvLaunch* launch, float* dw, float* colsum, int split_rows,
                             void* stream);
 
+/* Deterministic split-K variant: every pixel chunk writes its partial dW tile with plain stores into
+ * slab `chunk` of the workspace (ws + chunk*slab_stride floats; slab_stride >= K*T*C), to be summed in
+ * a fixed order by mi355_slab_reduce.  Plain stores run ~4-5x the fp32-atomic rate and the result is
+ * bit-reproducible.  max_slabs = capacity of ws; mi355_conv_wgrad_num_slabs gives the count. */
+int mi355_conv_wgrad_num_slabs(const Mi355ConvLaunch* launch, int split_rows, int* nslabs);
+int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* ws, int64_t slab_stride, int max_slabs,
+                           float* colsum, int split_rows, void* stream);
+/* out[i] (+)= sum_s ws[s*slab_stride + i], i < n (n, slab_stride multiples of 4; 16-B aligned) */
+int mi355_slab_reduce(const float* ws, int nslabs, int64_t slab_stride, int64_t n, float* out,
+                      int accumulate, void* stream);
+
 /* ---- elementwise / layout helpers of the conv path --------------------------------------- */
 /* fp32 NCHW [N][C][H][W] -> bf16 NHWC [N][H][W][Cpad] (channels >= C zero). */
 int mi355_nchw_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int W, int Cpad,

@@ -44,16 +44,21 @@ int mi355_dw_param_grads(const float* G_t, const float* w, const float* scale, c
                          float* dgamma, float* dbeta, int accumulate, void* stream);
 
 /* squeeze-excite (efficientnet.py:98-104) */
-int mi355_se_pool(const void* z, int in_swish, float* pool /* [N][C], zeroed */, int N, int HW, int C,
+/* The H*W reduction is split into `slabs` row slabs per sample (mi355_se_slabs); the reduce kernels
+ * store per-slab partials [N][slabs][C] (no atomics, nothing to zero) and the tiny per-sample FC
+ * kernels add them in a fixed order: bit-reproducible forward and backward. */
+int mi355_se_slabs(int N, int HW, int* slabs);
+int mi355_se_pool(const void* z, int in_swish, float* pool_partial /* [N][slabs][C] */, int N, int HW, int C,
                   void* stream);
-int mi355_se_fc(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2,
-                float* rpre /* [N][Cse] */, float* gate /* [N][C] */, int N, int C, int Cse, void* stream);
+int mi355_se_fc(const float* pool_partial, int slabs, float* pool /* [N][C] out */, const float* w1,
+                const float* b1, const float* w2, const float* b2, float* rpre /* [N][Cse] */,
+                float* gate /* [N][C] */, int N, int C, int Cse, void* stream);
 int mi355_se_scale(const void* z, const float* gate, void* u, int N, int HW, int C, void* stream);
-int mi355_se_bwd_reduce(const void* gu, const void* z, float* ggate /* [N][C], zeroed */, int N, int HW,
+int mi355_se_bwd_reduce(const void* gu, const void* z, float* ggate_partial /* [N][slabs][C] */, int N, int HW,
                         int C, void* stream);
 int mi355_se_fc_bwd(const float* pool, const float* w1, const float* w2, const float* rpre,
-                    const float* gate, const float* ggate, float* gpool, float* dw1, float* db1,
-                    float* dw2, float* db2, int N, int C, int Cse, void* stream);
+                    const float* gate, const float* ggate_partial, int slabs, float* gpool, float* dw1,
+                    float* db1, float* dw2, float* db2, int N, int C, int Cse, void* stream);
 int mi355_se_bwd_apply(const void* gu, const void* z, const float* gate, const float* gpool, void* gz,
                        int N, int HW, int C, void* stream);
 

@@ -41,6 +41,7 @@ struct WLaunch {
     WProb p[MI355_CONV_MAX_PROBLEMS];
     float* dw;
     float* colsum;
+    long long slab_stride;      // > 0: plain stores into slab `chunk` (dw + chunk*slab_stride), reduced later
     int nprob, K, T, k_tiles, c_tiles, ntaps, split_rows;
 };
 
@@ -219,11 +220,48 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
         if (k >= L.K) break;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-            if (coff[h] >= 0) atomicAdd(L.dw + k * wrow + coff[h], epi[rr * EPI_LD + h * 64 + lane]);
+            if (coff[h] >= 0) {
+                float* dst = L.dw + k * wrow + coff[h];
+                const float v = epi[rr * EPI_LD + h * 64 + lane];
+                if (L.slab_stride > 0) dst[(long long)chunk * L.slab_stride] = v;   // deterministic split-K
+                else atomicAdd(dst, v);
+            }
     }
 }
 
 }  // namespace
+
+template <bool ALIGNED>
+__global__ void slab_reduce_kernel(const float4* __restrict__ ws, int nslabs, long long slab4, long long n4,
+                                   float* __restrict__ out, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (accumulate) {
+        if (ALIGNED) a = reinterpret_cast<const float4*>(out)[i];
+        else a = make_float4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+    }
+    for (int s = 0; s < nslabs; ++s) {                       // fixed order: bit-reproducible
+        const float4 v = ws[(long long)s * slab4 + i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (ALIGNED) reinterpret_cast<float4*>(out)[i] = a;
+    else { out[4 * i] = a.x; out[4 * i + 1] = a.y; out[4 * i + 2] = a.z; out[4 * i + 3] = a.w; }
+}
+
+extern "C" int mi355_slab_reduce(const float* ws, int nslabs, int64_t slab_stride, int64_t n, float* out,
+                                 int accumulate, void* stream) {
+    MI355_REQUIRE(ws && out && nslabs > 0 && n > 0 && n % 4 == 0 && slab_stride % 4 == 0, "slab_reduce: bad args");
+    MI355_REQUIRE(((uintptr_t)ws & 15) == 0, "slab_reduce: workspace alignment");
+    const dim3 g((unsigned)cdiv(n / 4, 256)), b(256);
+    if (((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL(slab_reduce_kernel<true>, g, b, 0, (hipStream_t)stream, (const float4*)ws, nslabs,
+                           (long long)(slab_stride / 4), (long long)(n / 4), out, accumulate);
+    else
+        hipLaunchKernelGGL(slab_reduce_kernel<false>, g, b, 0, (hipStream_t)stream, (const float4*)ws, nslabs,
+                           (long long)(slab_stride / 4), (long long)(n / 4), out, accumulate);
+    return check_launch("slab_reduce_kernel");
+}
 
 extern "C" int mi355_conv_wgrad(const Mi355ConvLaunch* launch, float* dw, int split_rows, void* stream) {
     return mi355_conv_wgrad_colsum(launch, dw, nullptr, split_rows, stream);
@@ -231,6 +269,22 @@ extern "C" int mi355_conv_wgrad(const Mi355ConvLaunch* launch, float* dw, int sp
 
 extern "C" int mi355_conv_wgrad_colsum(const Mi355ConvLaunch* launch, float* dw, float* colsum,
                                        int split_rows, void* stream) {
+    return mi355_conv_wgrad_slabs(launch, dw, 0, 0, colsum, split_rows, stream);
+}
+
+extern "C" int mi355_conv_wgrad_num_slabs(const Mi355ConvLaunch* launch, int split_rows, int* nslabs) {
+    MI355_REQUIRE(launch && nslabs && split_rows > 0, "conv_wgrad_num_slabs: bad args");
+    int chunks = 0;
+    for (int i = 0; i < launch->nprob; ++i) {
+        const Mi355ConvProblem& s = launch->prob[i];
+        chunks += (int)cdiv((long long)s.N * s.P * s.Q, split_rows);
+    }
+    *nslabs = chunks;
+    return MI355_OK;
+}
+
+extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, int64_t slab_stride,
+                                      int max_slabs, float* colsum, int split_rows, void* stream) {
     MI355_REQUIRE(launch && dw, "conv_wgrad: null argument");
     const Mi355ConvLaunch& in = *launch;
     MI355_REQUIRE(in.nprob >= 1 && in.nprob <= MI355_CONV_MAX_PROBLEMS, "conv_wgrad: nprob");
@@ -267,6 +321,8 @@ extern "C" int mi355_conv_wgrad_colsum(const Mi355ConvLaunch* launch, float* dw,
     if (ntaps == 0) return MI355_OK;
     L.dw = dw;
     L.colsum = colsum;
+    L.slab_stride = slab_stride;
+    MI355_REQUIRE(slab_stride == 0 || chunks <= max_slabs, "conv_wgrad_slabs: %d slabs > workspace for %d", chunks, max_slabs);
     L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.ntaps = ntaps; L.split_rows = split_rows;
     const bool flat = C < TC;
     L.k_tiles = (int)cdiv(in.K, TK);

@@ -316,7 +316,8 @@ extern "C" int mi355_dw_param_grads(const float* G_t, const float* w, const floa
 }
 
 // ============================================================================ squeeze-excite
-// pool[n][c] += (1/HW) * sum over a slab of pixels; grid (slabs, N)
+// partial[n][slab][c] = scale * sum over a slab of pixels (summed in a fixed order by the consumer:
+// bit-reproducible, no atomics, nothing to zero); grid (slabs, N)
 template <bool SWISH, bool MUL>
 __global__ __launch_bounds__(256) void se_reduce_kernel(const unsigned short* __restrict__ a,
                                                         const unsigned short* __restrict__ z, float* __restrict__ out,
@@ -356,12 +357,12 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const unsigned short* __
             for (int c = tid; c < C; c += 256) {
                 float t = 0.0f;
                 for (int r = 0; r < nphase; ++r) t += s_acc[r * C + c];
-                atomicAdd(out + (long long)n * C + c, t * scale);
+                out[((long long)n * gridDim.x + blockIdx.x) * C + c] = t * scale;   // slab partial: no atomics
             }
             __syncthreads();
         } else if (c8 < c8n) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(out + (long long)n * C + c8 * 8 + e, acc[e] * scale);
+            for (int e = 0; e < 8; ++e) out[((long long)n * gridDim.x + blockIdx.x) * C + c8 * 8 + e] = acc[e] * scale;
         }
     }
 }
@@ -372,6 +373,14 @@ static void se_grid(int N, int HW, int* rows, dim3* grid) {
     if (slabs < 1) slabs = 1;
     *rows = (HW + slabs - 1) / slabs;
     *grid = dim3((unsigned)slabs, (unsigned)N);
+}
+
+extern "C" int mi355_se_slabs(int N, int HW, int* slabs) {
+    MI355_REQUIRE(N > 0 && HW > 0 && slabs, "se_slabs: bad args");
+    int rows; dim3 grid;
+    se_grid(N, HW, &rows, &grid);
+    *slabs = (int)grid.x;
+    return MI355_OK;
 }
 
 extern "C" int mi355_se_pool(const void* z, int in_swish, float* pool, int N, int HW, int C, void* stream) {
@@ -398,7 +407,8 @@ extern "C" int mi355_se_bwd_reduce(const void* gu, const void* z, float* ggate, 
 }
 
 // one block per sample: r = swish(W1 pool + b1); gate = sigmoid(W2 r + b2)
-__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ part, int slabs,
+                                                    float* __restrict__ pool, const float* __restrict__ w1,
                                                     const float* __restrict__ b1, const float* __restrict__ w2,
                                                     const float* __restrict__ b2, float* __restrict__ rpre,
                                                     float* __restrict__ gate, int C, int Cse) {
@@ -406,7 +416,12 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ po
     float* s_pool = sm;
     float* s_r = sm + C;
     const int n = blockIdx.x, tid = threadIdx.x;
-    for (int c = tid; c < C; c += 256) s_pool[c] = pool[(long long)n * C + c];
+    for (int c = tid; c < C; c += 256) {
+        float t = 0.0f;
+        for (int sl = 0; sl < slabs; ++sl) t += part[((long long)n * slabs + sl) * C + c];   // fixed order
+        s_pool[c] = t;
+        pool[(long long)n * C + c] = t;
+    }
     __syncthreads();
     for (int j = tid; j < Cse; j += 256) {
         float t = b1[j];
@@ -422,18 +437,20 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ po
     }
 }
 
-extern "C" int mi355_se_fc(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2,
-                           float* rpre, float* gate, int N, int C, int Cse, void* stream) {
-    MI355_REQUIRE(pool && w1 && b1 && w2 && b2 && rpre && gate && N > 0 && C > 0 && Cse > 0, "se_fc: bad args");
-    hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), (size_t)(C + Cse) * 4, (hipStream_t)stream, pool, w1, b1, w2,
-                       b2, rpre, gate, C, Cse);
+extern "C" int mi355_se_fc(const float* part, int slabs, float* pool, const float* w1, const float* b1,
+                           const float* w2, const float* b2, float* rpre, float* gate, int N, int C, int Cse,
+                           void* stream) {
+    MI355_REQUIRE(part && slabs > 0 && pool && w1 && b1 && w2 && b2 && rpre && gate && N > 0 && C > 0 && Cse > 0,
+                  "se_fc: bad args");
+    hipLaunchKernelGGL(se_fc_kernel, dim3(N), dim3(256), (size_t)(C + Cse) * 4, (hipStream_t)stream, part, slabs, pool,
+                       w1, b1, w2, b2, rpre, gate, C, Cse);
     return check_launch("se_fc_kernel");
 }
 
 __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
                                                         const float* __restrict__ w2, const float* __restrict__ rpre,
                                                         const float* __restrict__ gate, const float* __restrict__ ggate,
-                                                        float* __restrict__ gpool, float* __restrict__ dw1,
+                                                        int slabs, float* __restrict__ gpool, float* __restrict__ dw1,
                                                         float* __restrict__ db1, float* __restrict__ dw2,
                                                         float* __restrict__ db2, int C, int Cse) {
     extern __shared__ float sm[];                  // pool[C] | de[C] | r[Cse] | drpre[Cse]
@@ -445,7 +462,9 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict_
     for (int c = tid; c < C; c += 256) {
         s_pool[c] = pool[(long long)n * C + c];
         const float g = gate[(long long)n * C + c];
-        const float de = ggate[(long long)n * C + c] * g * (1.0f - g);
+        float gg = 0.0f;
+        for (int sl = 0; sl < slabs; ++sl) gg += ggate[((long long)n * slabs + sl) * C + c];   // fixed order
+        const float de = gg * g * (1.0f - g);
         s_de[c] = de;
         atomicAdd(db2 + c, de);
     }
@@ -475,12 +494,12 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict_
 }
 
 extern "C" int mi355_se_fc_bwd(const float* pool, const float* w1, const float* w2, const float* rpre,
-                               const float* gate, const float* ggate, float* gpool, float* dw1, float* db1,
-                               float* dw2, float* db2, int N, int C, int Cse, void* stream) {
+                               const float* gate, const float* ggate, int slabs, float* gpool, float* dw1,
+                               float* db1, float* dw2, float* db2, int N, int C, int Cse, void* stream) {
     MI355_REQUIRE(pool && w1 && w2 && rpre && gate && ggate && gpool && dw1 && db1 && dw2 && db2 && N > 0 && C > 0 &&
                   Cse > 0, "se_fc_bwd: bad args");
     hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(N), dim3(256), (size_t)(2 * C + 2 * Cse) * 4, (hipStream_t)stream, pool,
-                       w1, w2, rpre, gate, ggate, gpool, dw1, db1, dw2, db2, C, Cse);
+                       w1, w2, rpre, gate, ggate, slabs, gpool, dw1, db1, dw2, db2, C, Cse);
     return check_launch("se_fc_bwd_kernel");
 }
 

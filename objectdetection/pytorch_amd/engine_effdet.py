@@ -207,25 +207,29 @@ class EffDetPlan(RetinaPlan):
     def se_op(self, spec, z):
         N, H, W, C = z.shape
         HW = H * W
-        pool = self._zero_fwd_alloc(N * C).view(N, C)
+        ns = ctypes.c_int()
+        _lib.call('mi355_se_slabs', c_int(N), c_int(HW), ctypes.byref(ns))
+        slabs = ns.value
+        part = self.new((N, slabs, C), torch.float32)
+        pool = self.new((N, C), torch.float32)
         rpre = self.new((N, spec.Cse), torch.float32)
         gate = self.new((N, C), torch.float32)
         u = self.new(tuple(z.shape))
         w1, b1, w2, b2 = spec.reduce.weight, spec.reduce.bias, spec.expand.weight, spec.expand.bias
         dims = (c_int(N), c_int(HW), c_int(C))
-        self._step(self.fwd_steps, 'mi355_se_pool', ptr(z), c_int(1), ptr(pool), *dims)
-        self._step(self.fwd_steps, 'mi355_se_fc', ptr(pool), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(rpre), ptr(gate),
-                   c_int(N), c_int(C), c_int(spec.Cse))
+        self._step(self.fwd_steps, 'mi355_se_pool', ptr(z), c_int(1), ptr(part), *dims)
+        self._step(self.fwd_steps, 'mi355_se_fc', ptr(part), c_int(slabs), ptr(pool), ptr(w1), ptr(b1), ptr(w2),
+                   ptr(b2), ptr(rpre), ptr(gate), c_int(N), c_int(C), c_int(spec.Cse))
         self._step(self.fwd_steps, 'mi355_se_scale', ptr(z), ptr(gate), ptr(u), *dims)
 
         def bwd():
             if not self.has_grad(u):
                 return
             gu = self.grad(u)
-            ggate = self._zero_bwd_alloc(N * C).view(N, C)
+            ggate = self.new((N, slabs, C), torch.float32)
             gpool = self.new((N, C), torch.float32)
             self._step(self.bwd_steps, 'mi355_se_bwd_reduce', ptr(gu), ptr(z), ptr(ggate), *dims)
-            self._se_bwd.append((spec, pool, rpre, gate, ggate, gpool, N))
+            self._se_bwd.append((spec, pool, rpre, gate, ggate, gpool, N, slabs))
             self._step(self.bwd_steps, '__se_fc_bwd__', len(self._se_bwd) - 1)
             gz = self.grad(z)
             assert self.first_write(z)
@@ -460,9 +464,9 @@ class EffDetPlan(RetinaPlan):
         for fn, args, name in steps:
             if fn is None:
                 if name == '__se_fc_bwd__':
-                    spec, pool, rpre, gate, ggate, gpool, N = self._se_bwd[args[0]]
+                    spec, pool, rpre, gate, ggate, gpool, N, slabs = self._se_bwd[args[0]]
                     rc = lib.mi355_se_fc_bwd(ptr(pool), ptr(spec.reduce.weight), ptr(spec.expand.weight), ptr(rpre),
-                                             ptr(gate), ptr(ggate), ptr(gpool),
+                                             ptr(gate), ptr(ggate), c_int(slabs), ptr(gpool),
                                              ptr(self.grad_view(spec.reduce.weight, arena)),
                                              ptr(self.grad_view(spec.reduce.bias, arena)),
                                              ptr(self.grad_view(spec.expand.weight, arena)),

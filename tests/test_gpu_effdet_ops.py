@@ -93,23 +93,27 @@ def test_squeeze_excite_fwd_bwd():
     u.backward(gu)
     zh, guh = _nhwc(z.detach()), _nhwc(gu)
     dev = DEV
-    pool = torch.zeros((N, C), device=dev)
-    call('mi355_se_pool', ptr(zh), c_int(1), ptr(pool), c_int(N), c_int(H * W), c_int(C), stream_of(zh))
-    _close(pool, sq.detach().reshape(N, C), 2e-3)
+    ns = ctypes.c_int()
+    call('mi355_se_slabs', c_int(N), c_int(H * W), ctypes.byref(ns))
+    slabs = ns.value
+    part = torch.full((N, slabs, C), float('nan'), device=dev)       # nothing needs zeroing
+    pool = torch.empty((N, C), device=dev)
+    call('mi355_se_pool', ptr(zh), c_int(1), ptr(part), c_int(N), c_int(H * W), c_int(C), stream_of(zh))
     rpre = torch.empty((N, Cse), device=dev)
     g = torch.empty((N, C), device=dev)
     W1, B1, W2, B2 = [t.detach().to(dev).contiguous() for t in (w1, b1, w2, b2)]
-    call('mi355_se_fc', ptr(pool), ptr(W1), ptr(B1), ptr(W2), ptr(B2), ptr(rpre), ptr(g), c_int(N), c_int(C),
-         c_int(Cse), stream_of(zh))
+    call('mi355_se_fc', ptr(part), c_int(slabs), ptr(pool), ptr(W1), ptr(B1), ptr(W2), ptr(B2), ptr(rpre), ptr(g),
+         c_int(N), c_int(C), c_int(Cse), stream_of(zh))
+    _close(pool, sq.detach().reshape(N, C), 2e-3)
     _close(g, gate.detach().reshape(N, C), 2e-3)
     uh = torch.empty_like(zh)
     call('mi355_se_scale', ptr(zh), ptr(g), ptr(uh), c_int(N), c_int(H * W), c_int(C), stream_of(zh))
     _close(uh.permute(0, 3, 1, 2), u.detach(), 1e-2)
-    ggate = torch.zeros((N, C), device=dev)
+    ggate = torch.full((N, slabs, C), float('nan'), device=dev)
     call('mi355_se_bwd_reduce', ptr(guh), ptr(zh), ptr(ggate), c_int(N), c_int(H * W), c_int(C), stream_of(zh))
     gpool = torch.empty((N, C), device=dev)
     dW1, dB1, dW2, dB2 = [torch.zeros_like(t) for t in (W1, B1, W2, B2)]
-    call('mi355_se_fc_bwd', ptr(pool), ptr(W1), ptr(W2), ptr(rpre), ptr(g), ptr(ggate), ptr(gpool), ptr(dW1),
+    call('mi355_se_fc_bwd', ptr(pool), ptr(W1), ptr(W2), ptr(rpre), ptr(g), ptr(ggate), c_int(slabs), ptr(gpool), ptr(dW1),
          ptr(dB1), ptr(dW2), ptr(dB2), c_int(N), c_int(C), c_int(Cse), stream_of(zh))
     gz = torch.empty_like(zh)
     call('mi355_se_bwd_apply', ptr(guh), ptr(zh), ptr(g), ptr(gpool), ptr(gz), c_int(N), c_int(H * W), c_int(C),
