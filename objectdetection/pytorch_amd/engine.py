@@ -251,7 +251,8 @@ class RetinaPlan(object):
         L.nprob, L.K, L.T = len(problems), spec.Kpad, spec.T
         slab = spec.Kpad * spec.T * spec.Cpad
         tiles = ops_conv.wgrad_tiles(spec.Kpad, spec.Cpad, spec.T)
-        split = pick_split_rows(rows, tiles, target_blocks=512, min_rows=512)
+        split = pick_split_rows(rows, tiles, target_blocks=int(os.environ.get('MI355_WG_BLOCKS', '512')),
+                                min_rows=int(os.environ.get('MI355_WG_MINROWS', '512')))
         self.keep.append(L)
         spec._wgrad_launch = L
         if not self.deterministic:
