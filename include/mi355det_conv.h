@@ -112,6 +112,39 @@ int mi355_conv_param_grads(const float* G, const float* w, int64_t sk, int64_t s
                            const float* colsum, const float* mean, const float* var, float eps,
                            float* dW, float* dgamma, float* dbeta, int accumulate,
                            const float* conv_bias, float* dconv_bias, void* stream);
+/* ---- table-driven (one launch for ALL layers) weight prep and parameter-gradient finishing ----
+ * The per-layer entry points above cost ~5 us of GPU time each for ~125 + ~55 tiny launches per
+ * step; these two take a device-resident table of descriptors and cover every layer in one launch.
+ * nblocks = sum of the per-layer block counts (prep: ceil(Cpad/32)*ceil(Kpad/32)*R*S; grads: K);
+ * `block_begin` of each descriptor is the running sum.  The table is plain data: build it once. */
+typedef struct Mi355LayerDesc {
+    const float* w;          /* fp32 master weight [K][C][R][S], element strides sk,sc,sr,ss */
+    int64_t sk, sc, sr, ss;
+    int32_t K, C, R, S, Cpad, Kpad;
+    int32_t block_begin;     /* first block of this layer in the launch */
+    float eps;
+    int32_t atomic;          /* grads: != 0 when another descriptor writes the same dW / dbias
+                                (weights shared across pyramid levels): use atomics */
+    int32_t reserved;
+    const float* gamma;      /* frozen BN (all four NULL when the layer has no BN) */
+    const float* beta;
+    const float* mean;
+    const float* var;
+    const float* conv_bias;  /* conv bias in front of the BN, or NULL */
+    float* scale;            /* prep out: fp32 [K] (NULL without BN) */
+    float* shift;
+    void* w_fwd;             /* prep out: bf16 [K][R*S][Cpad] */
+    void* w_dgr;             /* prep out: bf16 [C][R*S][Kpad] or NULL */
+    const float* G;          /* grads in: raw wgrad fp32 [Kpad][R*S][Cpad] */
+    const float* colsum;     /* grads in: fp32 [Kpad] */
+    float* dW;               /* grads out (+=): same strides as w */
+    float* dgamma;           /* (+=) or NULL */
+    float* dbeta;            /* (+=): BN beta, or the conv bias of a BN-less layer, or NULL */
+    float* dconv_bias;       /* (+=) or NULL */
+} Mi355LayerDesc;
+int mi355_prep_weights_table(const Mi355LayerDesc* d_table, int nlayers, int nblocks, void* stream);
+int mi355_param_grads_table(const Mi355LayerDesc* d_table, int nlayers, int nblocks, void* stream);
+
 /* MaxPool 3x3 s2 p1 (retinanet.py:188) NHWC bf16; idx int8 [N][P][Q][C] = argmax window slot. */
 int mi355_maxpool3x3s2_fwd(const void* in, void* out, int8_t* idx, int N, int H, int W, int C,
                            void* stream);

@@ -355,3 +355,106 @@ extern "C" int mi355_relu_mask_bf16(const void* x, const void* ref, void* y, int
                        (const s8v*)x, (const s8v*)ref, (s8v*)y, (long long)(n / 8));
     return check_launch("relu_mask_kernel");
 }
+
+// ----------------------------------------------------------------------- table-driven variants
+__device__ __forceinline__ int find_layer(const Mi355LayerDesc* __restrict__ t, int nlayers, int b) {
+    int lo = 0, hi = nlayers - 1;                 // last layer with block_begin <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t[mid].block_begin <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void prep_weights_table_kernel(const Mi355LayerDesc* __restrict__ table,
+                                                                 int nlayers) {
+    __shared__ float tile[32][33];
+    __shared__ float s_scale[32];
+    const Mi355LayerDesc d = table[find_layer(table, nlayers, blockIdx.x)];
+    int b = blockIdx.x - d.block_begin;
+    const int ct = (d.Cpad + 31) / 32, kt = (d.Kpad + 31) / 32;
+    const int c_tile = b % ct;  b /= ct;
+    const int k_tile = b % kt;  b /= kt;
+    const int rs = b, T = d.R * d.S, r = rs / d.S, s = rs - r * d.S;
+    const int k0 = k_tile * 32, c0 = c_tile * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (threadIdx.x < 32) {
+        const int k = k0 + threadIdx.x;
+        float sc = 1.0f;
+        if (d.gamma && k < d.K) {
+            sc = d.gamma[k] / sqrtf(d.var[k] + d.eps);
+            if (rs == 0 && c_tile == 0) {
+                d.scale[k] = sc;
+                d.shift[k] = d.beta[k] - (d.mean[k] - (d.conv_bias ? d.conv_bias[k] : 0.0f)) * sc;
+            }
+        }
+        s_scale[threadIdx.x] = sc;
+    }
+    __syncthreads();
+    unsigned short* w_fwd = (unsigned short*)d.w_fwd;
+    unsigned short* w_dgr = (unsigned short*)d.w_dgr;
+    for (int j = ty; j < 32; j += 8) {
+        const int k = k0 + j, c = c0 + tx;
+        float v = 0.0f;
+        if (k < d.K && c < d.C) v = d.w[k * d.sk + c * d.sc + r * d.sr + s * d.ss] * s_scale[j];
+        tile[j][tx] = v;
+        if (k < d.K && c < d.Cpad) w_fwd[((long long)k * T + rs) * d.Cpad + c] = f32_to_bf16_rn(v);
+    }
+    __syncthreads();
+    if (w_dgr) {
+        for (int j = ty; j < 32; j += 8) {
+            const int c = c0 + j, k = k0 + tx;
+            if (c < d.C && k < d.Kpad) w_dgr[((long long)c * T + rs) * d.Kpad + k] = f32_to_bf16_rn(tile[tx][j]);
+        }
+    }
+}
+
+extern "C" int mi355_prep_weights_table(const Mi355LayerDesc* d_table, int nlayers, int nblocks, void* stream) {
+    MI355_REQUIRE(d_table && nlayers > 0 && nblocks > 0, "prep_weights_table: bad args");
+    hipLaunchKernelGGL(prep_weights_table_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
+                       d_table, nlayers);
+    return check_launch("prep_weights_table_kernel");
+}
+
+__global__ __launch_bounds__(256) void param_grads_table_kernel(const Mi355LayerDesc* __restrict__ table,
+                                                                int nlayers) {
+    const Mi355LayerDesc d = table[find_layer(table, nlayers, blockIdx.x)];
+    const int k = blockIdx.x - d.block_begin, tid = threadIdx.x;
+    const int T = d.R * d.S;
+    const float sck = d.gamma ? d.gamma[k] / sqrtf(d.var[k] + d.eps) : 1.0f;
+    float dot = 0.0f;
+    const int total = T * d.Cpad;
+    for (int i = tid; i < total; i += 256) {
+        const int t = i / d.Cpad, c = i - t * d.Cpad;
+        if (c >= d.C) continue;
+        const int r = t / d.S, s = t - r * d.S;
+        const float gv = d.G[(long long)k * total + i];
+        const long long wo = k * d.sk + c * d.sc + r * d.sr + s * d.ss;
+        if (d.dgamma) dot += d.w[wo] * gv;
+        if (d.atomic) atomicAdd(d.dW + wo, gv * sck); else d.dW[wo] += gv * sck;
+    }
+    if (d.dgamma || d.dbeta || d.dconv_bias) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = dot;
+        __syncthreads();
+        if (tid == 0) {
+            const float cs = d.colsum[k];
+            if (d.dgamma) {
+                const float invstd = 1.0f / sqrtf(d.var[k] + d.eps);
+                const float mu = d.mean[k] - (d.conv_bias ? d.conv_bias[k] : 0.0f);
+                d.dgamma[k] += invstd * ((red[0] + red[1] + red[2] + red[3]) - mu * cs);
+            }
+            if (d.dbeta) { if (d.atomic) atomicAdd(d.dbeta + k, cs); else d.dbeta[k] += cs; }
+            if (d.dconv_bias) { if (d.atomic) atomicAdd(d.dconv_bias + k, sck * cs); else d.dconv_bias[k] += sck * cs; }
+        }
+    }
+}
+
+extern "C" int mi355_param_grads_table(const Mi355LayerDesc* d_table, int nlayers, int nblocks, void* stream) {
+    MI355_REQUIRE(d_table && nlayers > 0 && nblocks > 0, "param_grads_table: bad args");
+    hipLaunchKernelGGL(param_grads_table_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream,
+                       d_table, nlayers);
+    return check_launch("param_grads_table_kernel");
+}

@@ -214,18 +214,43 @@ class RetinaPlan(object):
                 so += n + s.Kpad
 
     # ------------------------------------------------------------------ prep (per step)
+    def _layer_desc(self, s, arena=None):
+        """Mi355LayerDesc of one conv layer (prep fields; gradient fields when `arena` is given)."""
+        d = ops_conv.LayerDesc()
+        w = s.conv.weight
+        d.w = w.data_ptr()
+        d.sk, d.sc, d.sr, d.ss = w.stride()
+        d.K, d.C, d.R, d.S, d.Cpad, d.Kpad = s.K, s.C, s.R, s.S, s.Cpad, s.Kpad
+        bn = s.bn
+        if bn is not None:
+            d.gamma, d.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+            d.mean, d.var, d.eps = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.eps
+            d.conv_bias = s.conv.bias.data_ptr() if s.conv.bias is not None else 0
+            d.scale, d.shift = s.scale.data_ptr(), s.shift.data_ptr()
+        d.w_fwd = s.w_fwd.data_ptr()
+        d.w_dgr = s.w_dgr.data_ptr() if s.w_dgr is not None else 0
+        if arena is not None:
+            d.G, d.colsum = s.G.data_ptr(), s.colsum.data_ptr()
+            d.dW = self.grad_view(w, arena).data_ptr()
+            if bn is not None:
+                d.dgamma = self.grad_view(bn.weight, arena).data_ptr()
+                d.dbeta = self.grad_view(bn.bias, arena).data_ptr()
+                d.dconv_bias = self.grad_view(s.conv.bias, arena).data_ptr() if s.conv.bias is not None else 0
+            elif s.conv.bias is not None:
+                d.dbeta = self.grad_view(s.conv.bias, arena).data_ptr()
+        return d
+
     def _build_prep(self):
+        """ONE launch: frozen-BN fold + bf16 forward / dgrad weight shadows of every conv layer."""
+        descs, nb = [], 0
         for s in self.specs:
-            w = s.conv.weight
-            if s.bn is not None:
-                bn = s.bn
-                self._step(self.prep_steps, 'mi355_bn_fold', ptr(bn.weight), ptr(bn.bias),
-                           ptr(bn.running_mean), ptr(bn.running_var), ptr(s.conv.bias), c_f32(bn.eps),
-                           c_int(s.K), ptr(s.scale), ptr(s.shift))
-            sk, sc, sr, ss = w.stride()
-            self._step(self.prep_steps, 'mi355_prep_weight', ptr(w), c_i64(sk), c_i64(sc), c_i64(sr),
-                       c_i64(ss), c_int(s.K), c_int(s.C), c_int(s.R), c_int(s.S), c_int(s.Cpad),
-                       ptr(s.scale), ptr(s.w_fwd), ptr(s.w_dgr))
+            d = self._layer_desc(s)
+            d.block_begin = nb
+            nb += (-(-s.Cpad // 32)) * (-(-s.Kpad // 32)) * s.R * s.S
+            descs.append(d)
+        self.prep_table = ops_conv.upload_table(descs, self.dev)
+        self.bufs.append(self.prep_table)
+        self._step(self.prep_steps, 'mi355_prep_weights_table', ptr(self.prep_table), c_int(len(descs)), c_int(nb))
 
     # ------------------------------------------------------------------ launch builders
     def _gather(self, lst, problems, weight, K, T, bias=None, act=ACT_NONE, out_f32=False, flags=0):
@@ -512,34 +537,31 @@ class RetinaPlan(object):
                 self._gather(self.bwd_steps, probs, spec.w_dgr, 256, 9)
 
     def _build_param_grads(self):
-        """BN-folded layers (and padded ones): dW = G*scale, dgamma, dbeta from the raw wgrad."""
-        self.pgrad_args = []
-        for s in self.specs:
-            if s.direct:
-                continue
-            self.pgrad_args.append(s)
+        """BN-folded layers (and padded ones): dW = G*scale, dgamma, dbeta from the raw wgrad —
+        ONE table-driven launch per step (table built lazily per gradient arena)."""
+        self.pgrad_specs = [s for s in self.specs if not s.direct]
+        self.pgrad_tables = {}
 
     def _run_param_grads(self, arena, stream):
-        st = c_vp(stream)
-        for s in self.pgrad_args:
-            w = s.conv.weight
-            sk, sc, sr, ss = w.stride()
-            dW = self.grad_view(w, arena)
-            bn = s.bn
-            dgam = self.grad_view(bn.weight, arena) if bn is not None else None
-            dbet = (self.grad_view(bn.bias, arena) if bn is not None
-                    else (self.grad_view(s.conv.bias, arena) if s.conv.bias is not None else None))
-            cb = s.conv.bias if bn is not None else None          # conv bias in front of a BN
-            dcb = self.grad_view(cb, arena) if cb is not None else None
-            rc = self.lib.mi355_conv_param_grads(
-                ptr(s.G), ptr(w), c_i64(sk), c_i64(sc), c_i64(sr), c_i64(ss), c_int(s.K), c_int(s.C),
-                c_int(s.R), c_int(s.S), c_int(s.Cpad), ptr(s.scale), ptr(s.colsum),
-                ptr(bn.running_mean if bn is not None else None),
-                ptr(bn.running_var if bn is not None else None),
-                c_f32(bn.eps if bn is not None else 0.0), ptr(dW), ptr(dgam), ptr(dbet), c_int(1),   # arena zeroed: += handles shared convs
-                ptr(cb), ptr(dcb), st)
-            if rc:
-                raise _lib.Mi355Error('conv_param_grads(%s): %s' % (s.name, self.lib.mi355_last_error().decode()))
+        if not self.pgrad_specs:
+            return
+        tab = self.pgrad_tables.get(arena)
+        if tab is None:
+            self._carve_grads(arena)
+            seen, descs, nb = {}, [], 0
+            for s in self.pgrad_specs:
+                seen[id(s.conv)] = seen.get(id(s.conv), 0) + 1
+            for s in self.pgrad_specs:
+                d = self._layer_desc(s, arena)
+                d.atomic = 1 if seen[id(s.conv)] > 1 else 0
+                d.block_begin = nb
+                nb += s.K
+                descs.append(d)
+            tab = (ops_conv.upload_table(descs, self.dev), len(descs), nb)
+            self.pgrad_tables[arena] = tab
+        rc = self.lib.mi355_param_grads_table(ptr(tab[0]), c_int(tab[1]), c_int(tab[2]), c_vp(stream))
+        if rc:
+            raise _lib.Mi355Error('param_grads_table: %s' % self.lib.mi355_last_error().decode())
 
     # ------------------------------------------------------------------ execution
     def _stream(self):
