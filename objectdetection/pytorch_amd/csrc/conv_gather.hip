@@ -23,8 +23,7 @@ using namespace mi355;
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;          // 32 KiB
+constexpr int BN = 128, BK = 64;
 constexpr int EPI_LD = BN + 4;                           // fp32 staging row stride (floats): 64-row halves
 constexpr int EPI16_LD = BN + 4;                         // bf16 staging row stride (elements), 264 B
 constexpr int EPI_BYTES = 64 * EPI_LD * 4;               // 33792 B = 128 * EPI16_LD * 2 as well
@@ -61,11 +60,19 @@ __device__ __forceinline__ float activate(float v, int act) {
     return v;
 }
 
-// STAGES = 2: double-buffered k-loop, 64 KiB LDS, 2 blocks/CU (MFMA-bound shapes).
-// STAGES = 1: one stage, 32 KiB LDS, 4 blocks/CU: short reductions (<= 2 k-steps) are HBM-bound
-//             and live on bytes in flight, i.e. on resident blocks, not on intra-block overlap.
-template <bool FLAT, int STAGES>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDev L) {
+// WM = wave rows (each wave owns 64 x 64 outputs; 2 wave columns): tile = (WM*64) x 128, WM*128 threads.
+// <WM 2, STAGES 2>: 128x128, double-buffered k-loop, 64 KiB LDS, 2 blocks/CU.
+// <WM 2, STAGES 1>: one stage, 33 KiB LDS, 3-4 blocks/CU: short reductions (<= 2 k-steps) are HBM /
+//                   issue bound and live on resident blocks, not on intra-block overlap.
+// <WM 4, STAGES 3>: 256x128, 8 waves, 1 block/CU, THREE stages with a counted `s_waitcnt vmcnt` and a
+//                   raw s_barrier: the LDS-DMA of k-steps t+1 and t+2 stays in flight across the barrier
+//                   of k-step t (cdna_hip_programming.md §5 "Pipelining across barriers").
+template <bool FLAT, int STAGES, int WM>
+__global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDev L) {
+    constexpr int NTHREADS = WM * 128, BM = WM * 64;
+    constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = A_BYTES + BN * BK * 2;
+    constexpr int NB = 1024 / NTHREADS;               // B-tile DMA instructions per thread and stage
+    constexpr int ROWSTEP = NTHREADS / 8;             // rows covered by one DMA instruction of the block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ long long s_outoff[BM];
     __shared__ long long s_addoff[BM];
@@ -105,11 +112,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
     const int slot = tid & 7;
     const int kc = slot ^ ((tid >> 3) & 7);
     int a_base[4], a_ih0[4], a_iw0[4];
-    unsigned b_rowoff[4];
+    unsigned b_rowoff[NB];
     const int wrow = L.T * P.C;                       // elements per weight row
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 3) + 32 * i;
+        const int row = (tid >> 3) + ROWSTEP * i;
         const int m = m0 + row;
         {
             const int mc = min(m, P.M - 1);
@@ -119,8 +126,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
             a_iw0[i] = q * P.sw + P.dw0;
             a_base[i] = n * (int)P.in_sN + ((p * P.sh + P.dh0) * P.W + a_iw0[i]) * P.C;
         }
-        const int nn = n0 + row;
-        b_rowoff[i] = nn < L.K ? (unsigned)(nn * wrow) * 2u : OOB_OFFSET;
+        if (i < NB) {
+            const int nn = n0 + row;
+            b_rowoff[i] = nn < L.K ? (unsigned)(nn * wrow) * 2u : OOB_OFFSET;
+        }
     }
     const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(P.in, (unsigned)P.in_bytes);
     const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(L.w, (unsigned)L.w_bytes);
@@ -128,11 +137,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
     const int ntaps = P.TR * P.TS;
     const int cpt = P.C >> 3;                          // 16-B chunks per tap
     const int ksteps = FLAT ? (ntaps * cpt + 7) / 8 : ntaps * (P.C / BK);
-    const int csteps = FLAT ? 1 : P.C / BK;
 
+    // k-steps are issued strictly in order, so the (tap row, tap column, channel block) of the next
+    // stage is carried as wave-uniform counters instead of being decoded from ks by division.
+    int nx_ti = 0, nx_tj = 0, nx_c = 0;
     auto issue = [&](int ks, int buf) {
         unsigned char* sa = smem + buf * STAGE_BYTES;
-        unsigned char* sb = sa + BM * BK * 2;
+        unsigned char* sb = sa + A_BYTES;
         int ti, tj, c0;
         bool tap_ok = true;
         if (FLAT) {
@@ -143,10 +154,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
             tj = tap - ti * P.TS;
             tap_ok = tap < ntaps;
         } else {
-            const int tap = ks / csteps;               // wave-uniform
-            c0 = (ks - tap * csteps) * BK + kc * 8;
-            ti = tap / P.TS;
-            tj = tap - ti * P.TS;
+            ti = nx_ti;
+            tj = nx_tj;
+            c0 = nx_c + kc * 8;
+            nx_c += BK;
+            if (nx_c == P.C) {
+                nx_c = 0;
+                if (++nx_tj == P.TS) { nx_tj = 0; ++nx_ti; }
+            }
         }
         const int dh = ti * P.dhs, dw = tj * P.dws;
         const int a_delta = (dh * P.W + dw) * P.C + c0;
@@ -156,13 +171,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
             const bool ok = tap_ok && (unsigned)(a_ih0[i] + dh) < (unsigned)P.H &&
                             (unsigned)(a_iw0[i] + dw) < (unsigned)P.W;
             const unsigned off = ok ? (unsigned)(a_base[i] + a_delta) * 2u : OOB_OFFSET;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (LDS_PTR(void))(sa + (i * 256 + wv * 64) * 16),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (LDS_PTR(void))(sa + (i * NTHREADS + wv * 64) * 16),
                                                      16, off, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NB; ++i) {
             const unsigned off = (tap_ok && b_rowoff[i] != OOB_OFFSET) ? b_rowoff[i] + b_delta : OOB_OFFSET;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (LDS_PTR(void))(sb + (i * 256 + wv * 64) * 16),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (LDS_PTR(void))(sb + (i * NTHREADS + wv * 64) * 16),
                                                      16, off, 0, 0, 0);
         }
     };
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
     // ds_read_b128 byte offsets of this lane's fragments inside a stage (row r, chunk c):
     //   r*128 + ((c ^ (r & 7)) << 4); r & 7 == fr & 7 for every 16-row tile.
     const int a_rd = (wm * 64 + fr) * 128;
-    const int b_rd = BM * BK * 2 + (wn * 64 + fr) * 128;
+    const int b_rd = A_BYTES + (wn * 64 + fr) * 128;
     const int sw0 = ((fq) ^ (fr & 7)) << 4;           // k-sub 0: chunk fq
     const int sw1 = ((4 + fq) ^ (fr & 7)) << 4;       // k-sub 1: chunk 4 + fq
 
@@ -231,15 +246,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i][j] = b4[j];
     }
-    __syncthreads();
-    if (STAGES == 2) {
+    if (STAGES == 3) {
+        // three-stage ring: stage ks is read while ks+1 and ks+2 are in flight.  Per thread a stage is
+        // 4 + NB DMA instructions; `vmcnt(4 + NB)` therefore retires stage ks and leaves ks+1 flying.
+        if (ksteps > 1) issue(1, 1);
+        for (int ks = 0; ks < ksteps; ++ks) {
+            // (lgkmcnt(0): this wave's ds_reads of the buffer refilled below have landed)
+            if (ks + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + NB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();              // raw: no vmcnt(0) drain (unlike __syncthreads)
+            if (ks + 2 < ksteps) issue(ks + 2, (ks + 2) % 3);
+            compute(ks % 3);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else if (STAGES == 2) {
+        __syncthreads();
         for (int ks = 0; ks < ksteps; ++ks) {
             const int buf = ks & 1;
-            if (ks + 1 < ksteps) issue(ks + 1, buf ^ 1);
-            compute(buf);
+            if (ks + 1 < ksteps && !(L.flags & 256)) issue(ks + 1, buf ^ 1);
+            if (!(L.flags & 512)) compute(buf);
             __syncthreads();
         }
     } else {
+        __syncthreads();
         for (int ks = 0; ks < ksteps; ++ks) {
             compute(0);
             __syncthreads();
@@ -262,7 +292,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
         s8v mk[8];
 #pragma unroll
         for (int pass = 0; pass < 8; ++pass) {       // mask reads first: latency hides under staging
-            const int row = pass * 16 + (tid >> 4);
+            const int row = pass * (NTHREADS / 16) + (tid >> 4);
             oo[pass] = k0 < L.K ? s_outoff[row] : -1;
             mk[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
             if (P.mask && oo[pass] >= 0) mk[pass] = *reinterpret_cast<const s8v*>(P.mask + oo[pass] + k0);
@@ -280,7 +310,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
 #pragma unroll
         for (int pass = 0; pass < 8; ++pass) {
             if (oo[pass] < 0) continue;
-            const int row = pass * 16 + (tid >> 4);
+            const int row = pass * (NTHREADS / 16) + (tid >> 4);
             const s4v lo = *reinterpret_cast<const s4v*>(st16 + row * EPI16_LD + col);
             const s4v hi = *reinterpret_cast<const s4v*>(st16 + row * EPI16_LD + col + 4);
             s8v o = (s8v){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -295,13 +325,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
     }
     // GENERAL: fp32 staging in two 64-row halves (addend / fp32 output / ragged channel tails)
     float* epi = reinterpret_cast<float*>(smem);
+    constexpr int PH = 64 / (NTHREADS / 16);           // read passes per 64-row slice
+    for (int half = 0; half < WM; ++half) {
+        long long oo[PH];
+        s8v mk[PH], ad[PH];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        long long oo[4];
-        s8v mk[4], ad[4];
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int row = half * 64 + pass * 16 + (tid >> 4);
+        for (int pass = 0; pass < PH; ++pass) {
+            const int row = half * 64 + pass * (NTHREADS / 16) + (tid >> 4);
             oo[pass] = k0 < L.K ? s_outoff[row] : -1;
             mk[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
             ad[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
@@ -319,9 +349,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
         }
         __syncthreads();
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < PH; ++pass) {
             if (oo[pass] < 0) continue;
-            const int hrow = pass * 16 + (tid >> 4);
+            const int hrow = pass * (NTHREADS / 16) + (tid >> 4);
             const f4v v0 = *reinterpret_cast<const f4v*>(epi + hrow * EPI_LD + col);
             const f4v v1 = *reinterpret_cast<const f4v*>(epi + hrow * EPI_LD + col + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -365,7 +395,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_gather_kernel(const LaunchDe
                 }
             }
         }
-        if (half == 0) __syncthreads();
+        if (half + 1 < WM) __syncthreads();
     }
 }
 
@@ -379,12 +409,31 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
     LaunchDev L;
     memset(&L, 0, sizeof(L));
     int tiles = 0;
-    bool flat = false;
     const int C = in.prob[0].C;
+    MI355_REQUIRE(C > 0 && C % 8 == 0, "conv_gather: C must be a multiple of 8");
+    const bool flat = C % BK != 0;
+    // k-steps of the longest problem decide the pipeline depth; the 256-row / 3-stage variant runs one
+    // block per CU, so it needs a long reduction and enough tiles to cover the chip.
+    int max_ksteps = 0;
+    long long big_tiles = 0;
+    for (int i = 0; i < in.nprob; ++i) {
+        const int taps = in.prob[i].TR * in.prob[i].TS;
+        const int ks = flat ? (taps * (C / 8) + 7) / 8 : taps * (C / BK);
+        if (ks > max_ksteps) max_ksteps = ks;
+        big_tiles += cdiv((long long)in.prob[i].N * in.prob[i].P * in.prob[i].Q, 256);
+    }
+    const bool single = max_ksteps <= 2;
+    static const int big_min_grid = [] {
+        const char* e = getenv("MI355_GATHER_BIG");
+        return e ? atoi(e) : 256;
+    }();
+    const bool big = !flat && max_ksteps >= 6 && big_min_grid > 0 &&
+                     big_tiles * cdiv(in.K, BN) >= big_min_grid;
+    const int BM = big ? 256 : 128;
     for (int i = 0; i < in.nprob; ++i) {
         const Mi355ConvProblem& s = in.prob[i];
         MI355_REQUIRE(s.in && s.out, "conv_gather: problem %d null in/out", i);
-        MI355_REQUIRE(s.C == C && C > 0 && C % 8 == 0, "conv_gather: C must be a multiple of 8 and equal across problems");
+        MI355_REQUIRE(s.C == C, "conv_gather: C must be equal across problems");
         MI355_REQUIRE(s.N > 0 && s.H > 0 && s.W > 0 && s.P > 0 && s.Q > 0, "conv_gather: problem %d bad dims", i);
         MI355_REQUIRE(s.TR >= 0 && s.TS >= 0 && s.add_shift >= 0, "conv_gather: bad taps");
         const long long in_sN = s.in_sN ? s.in_sN : (long long)s.H * s.W * s.C;
@@ -409,39 +458,35 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
         d.tile_begin = tiles;
         tiles += (int)cdiv(d.M, BM);
     }
-    if (C % BK != 0) flat = true;
     const long long w_bytes = (long long)in.K * in.T * C * 2;
     MI355_REQUIRE(w_bytes < 0x7fffffffLL, "conv_gather: weight tensor >= 2 GiB");
     MI355_REQUIRE(((uintptr_t)in.weight & 15) == 0, "conv_gather: weight alignment");
     L.w = (const unsigned short*)in.weight;
     L.bias = in.bias;
     L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.act = in.act; L.out_f32 = in.out_f32; L.flags = in.flags;
+    { const char* e = getenv("MI355_DBG"); if (e) L.flags |= atoi(e); }
     L.n_tiles = (int)cdiv(in.K, BN);
     L.w_bytes = (int)w_bytes;
     const long long grid = (long long)tiles * L.n_tiles;
     MI355_REQUIRE(grid > 0 && grid < 0x7fffffffLL, "conv_gather: grid");
-    // k-steps of the longest problem decide the pipeline depth
-    int max_ksteps = 0;
-    for (int i = 0; i < in.nprob; ++i) {
-        const int taps = in.prob[i].TR * in.prob[i].TS;
-        const int ks = flat ? (taps * (C / 8) + 7) / 8 : taps * (C / BK);
-        if (ks > max_ksteps) max_ksteps = ks;
-    }
-    const bool single = max_ksteps <= 2;
+    constexpr int STAGE2 = (128 + BN) * BK * 2, STAGE3 = (256 + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);
+        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);
+        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
         attr_set = true;
     }
-    const dim3 g((unsigned)grid), b(NTHREADS);
+    const dim3 g((unsigned)grid);
     hipStream_t st = (hipStream_t)stream;
-    if (single) {
-        if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1>), g, b, EPI_BYTES, st, L);
-        else      hipLaunchKernelGGL((conv_gather_kernel<false, 1>), g, b, EPI_BYTES, st, L);
+    if (big) {
+        hipLaunchKernelGGL((conv_gather_kernel<false, 3, 4>), g, dim3(512), 3 * STAGE3, st, L);
+    } else if (single) {
+        if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
+        else      hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
     } else {
-        if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 2>), g, b, 2 * STAGE_BYTES, st, L);
-        else      hipLaunchKernelGGL((conv_gather_kernel<false, 2>), g, b, 2 * STAGE_BYTES, st, L);
+        if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 2, 2>), g, dim3(256), 2 * STAGE2, st, L);
+        else      hipLaunchKernelGGL((conv_gather_kernel<false, 2, 2>), g, dim3(256), 2 * STAGE2, st, L);
     }
     return check_launch("conv_gather_kernel");
 }

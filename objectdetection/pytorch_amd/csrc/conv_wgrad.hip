@@ -23,7 +23,9 @@ namespace {
 constexpr int TK = 128, TC = 128, RM = 64, NTHREADS = 256;
 constexpr int STAGE_BYTES = (TK + TC) * RM * 2;           // 32 KiB
 constexpr int EPI_LD = TC + 4;
-constexpr int LDS_BYTES = (2 * STAGE_BYTES > TK * EPI_LD * 4) ? 2 * STAGE_BYTES : TK * EPI_LD * 4;
+constexpr int TAB_STEPS = 8, TAB_ROWS = TAB_STEPS * RM;   // pixel-row table: 512 rows x 16 B behind the stages
+constexpr int TAB_OFF = 2 * STAGE_BYTES;
+constexpr int LDS_BYTES = (TAB_OFF + TAB_ROWS * 16 > TK * EPI_LD * 4) ? TAB_OFF + TAB_ROWS * 16 : TK * EPI_LD * 4;
 
 struct WProb {
     const unsigned short* in;
@@ -42,8 +44,24 @@ struct WLaunch {
     float* dw;
     float* colsum;
     long long slab_stride;      // > 0: plain stores into slab `chunk` (dw + chunk*slab_stride), reduced later
-    int nprob, K, T, k_tiles, c_tiles, ntaps, split_rows;
+    int nprob, K, T, k_tiles, c_tiles, ntaps, split_rows, dbg;
 };
+
+// Transposed LDS read as opaque inline asm.  hipcc orders a visible LDS read behind EVERY pending
+// LDS-DMA (`s_waitcnt vmcnt(0)`: it cannot tell the two stage buffers apart), which serialised the
+// prefetch of stage t+1 with the MFMAs of stage t.  The asm form is invisible to that pass; the stage
+// being read was retired by the `vmcnt(0)` + barrier that ended the previous iteration, and its own
+// completion is awaited with the explicit `lgkmcnt(0)` below.
+template <int OFF>
+__device__ __forceinline__ s4v lds_tr(unsigned addr) {
+    s4v v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs behind the wait (guide §5.4 rule 18)
+}
 
 template <bool FLAT>
 __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L) {
@@ -97,24 +115,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
         cx_ok = cx + 8 <= P.C;
     }
 
+    // Pixel-row table: the (image, row, column) decomposition of the block's pixel rows is computed once
+    // per 8 stages (2 rows per thread) instead of 4 rows per thread and stage; a stage then costs a
+    // 16-B LDS read, two bound checks and two adds per row.
+    //   .x = element offset of input pixel (p*sh, q*sw)   .y = (p*sh) << 16 | (q*sw)   .z = dy row offset
+    int4* tab = reinterpret_cast<int4*>(smem + TAB_OFF);
+    auto fill = [&](int step0) {
+        for (int e = tid; e < TAB_ROWS; e += NTHREADS) {
+            const int m = m_begin + step0 * RM + e;
+            int4 t = make_int4(0, 0x7fff0000, -1, 0);          // row beyond the chunk: never in range
+            if (m < m_end) {
+                const unsigned n = fdiv((unsigned)m, P.dPQ);
+                const unsigned rem = (unsigned)m - n * (unsigned)(P.P * P.Q);
+                const unsigned p = fdiv(rem, P.dQ);
+                const unsigned q = rem - p * (unsigned)P.Q;
+                const int ih0 = (int)p * P.sh, iw0 = (int)q * P.sw;
+                t.x = (int)n * P.in_sN + (ih0 * P.W + iw0) * P.C;
+                t.y = (ih0 << 16) | iw0;
+                t.z = (int)n * P.dy_sN + (int)rem * L.K;
+            }
+            tab[e] = t;
+        }
+    };
+    const int tapoff = (dh * P.W + dw) * P.C + cx;
     auto issue = [&](int step, int buf) {
         unsigned char* sy = smem + buf * STAGE_BYTES;
         unsigned char* sx = sy + TK * RM * 2;
+        int4 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = tab[(step & (TAB_STEPS - 1)) * RM + srow + 16 * i];   // before any DMA
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m_begin + step * RM + srow + 16 * i;
-            const bool mok = m < m_end;
-            unsigned offy = OOB_OFFSET, offx = OOB_OFFSET;
-            if (mok) {
-                const unsigned n = fdiv((unsigned)m, P.dPQ);
-                const unsigned rem = (unsigned)m - n * (unsigned)(P.P * P.Q);
-                if (ky_ok) offy = (unsigned)((int)n * P.dy_sN + (int)rem * L.K + ky) * 2u;
-                const unsigned p = fdiv(rem, P.dQ);
-                const unsigned q = rem - p * (unsigned)P.Q;
-                const int ih = (int)p * P.sh + dh, iw = (int)q * P.sw + dw;
-                if (cx_ok && (unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W)
-                    offx = (unsigned)((int)n * P.in_sN + (ih * P.W + iw) * P.C + cx) * 2u;
-            }
+            const int ih = (t[i].y >> 16) + dh, iw = (t[i].y & 0xffff) + dw;
+            const unsigned offy = (ky_ok && t[i].z >= 0) ? (unsigned)(t[i].z + ky) * 2u : OOB_OFFSET;
+            const unsigned offx = (cx_ok && (unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W)
+                                      ? (unsigned)(t[i].x + tapoff) * 2u : OOB_OFFSET;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (LDS_PTR(void))(sy + (i * 256 + wv * 64) * 16),
                                                      16, offy, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_PTR(void))(sx + (i * 256 + wv * 64) * 16),
@@ -135,45 +170,64 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
     const int row_lo = 8 * g + q4;
     // logical 16-B chunk of (tile t of this wave, p4): 8*wk + 2t + (p4 >> 1) for dy, 8*wc + ... for x
     const int half8 = (p4 & 1) * 8;
+    constexpr int XOFF = TK * RM * 2;                  // x tile behind the dy tile of a stage
+    const unsigned lds0 = (unsigned)(uintptr_t)(LDS_PTR(void))smem;
+    unsigned ady[4], adx[4];                           // byte offsets inside a stage (rows 0..31: +0 / +4 rows)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ady[t] = row_lo * 256 + ((8 * wk + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
+        adx[t] = row_lo * 256 + ((8 * wc + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
+    }
 
     // column sums of dy (bias / BN-beta gradient): only the blocks owning (tap 0, c-tile 0) and
     // only their wc == 0 waves (the other column-waves hold the same dy fragments)
     const bool do_colsum = L.colsum != nullptr && c_tile == 0 && tap == 0 && wc == 0;
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
     const int nsteps = (m_end - m_begin + RM - 1) / RM;
+    fill(0);
+    __syncthreads();
     if (nsteps > 0) issue(0, 0);
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
         const int buf = step & 1;
-        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
-        const unsigned char* sy = smem + buf * STAGE_BYTES;
-        const unsigned char* sx = sy + TK * RM * 2;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            s8v af[4], bf[4];
-            const int r0 = sub * 32 + row_lo;
+        if (((step + 1) & (TAB_STEPS - 1)) == 0 && step + 1 < nsteps) {
+            fill(step + 1);              // every table read of stages <= step happened before the last barrier
+            __syncthreads();
+        }
+        if (step + 1 < nsteps && !(L.dbg & 256)) issue(step + 1, buf ^ 1);
+        if (!(L.dbg & 512)) {
+            const unsigned sb = lds0 + buf * STAGE_BYTES;
+            s8v af[2][4], bf[2][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int cy = ((8 * wk + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
-                const int cxx = ((8 * wc + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
-                const s4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4v))(sy + r0 * 256 + cy));
-                const s4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4v))(sy + (r0 + 4) * 256 + cy));
-                const s4v b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4v))(sx + r0 * 256 + cxx));
-                const s4v b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s4v))(sx + (r0 + 4) * 256 + cxx));
-                af[t] = (s8v){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                bf[t] = (s8v){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                const s4v a0 = lds_tr<0>(sb + ady[t]), a1 = lds_tr<1024>(sb + ady[t]);
+                const s4v b0 = lds_tr<XOFF>(sb + adx[t]), b1 = lds_tr<XOFF + 1024>(sb + adx[t]);
+                af[0][t] = (s8v){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                bf[0][t] = (s8v){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
             }
-            if (do_colsum) {                           // wave-uniform
+            lds_wait();
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) csum[t] += bf16_to_f32((unsigned short)af[t][e]);
+            for (int t = 0; t < 4; ++t) {              // rows 32..63 fly while rows 0..31 are on the matrix cores
+                const s4v a0 = lds_tr<8192>(sb + ady[t]), a1 = lds_tr<8192 + 1024>(sb + ady[t]);
+                const s4v b0 = lds_tr<XOFF + 8192>(sb + adx[t]), b1 = lds_tr<XOFF + 8192 + 1024>(sb + adx[t]);
+                af[1][t] = (s8v){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                bf[1][t] = (s8v){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int sub = 0; sub < 2; ++sub) {
+                if (sub == 1) lds_wait();
+                if (do_colsum) {                       // wave-uniform
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) csum[t] += bf16_to_f32((unsigned short)af[sub][t][e]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[sub][i], bf[sub][j], acc[i][j], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -306,6 +360,7 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
         const long long dy_bytes = ((long long)(s.N - 1) * dy_sN + (long long)s.P * s.Q * in.K) * 2;
         MI355_REQUIRE(in_bytes < 0x7fffffffLL && dy_bytes < 0x7fffffffLL && M > 0, "conv_wgrad: tensor >= 2 GiB");
         MI355_REQUIRE(((uintptr_t)s.in & 15) == 0 && ((uintptr_t)s.out & 15) == 0, "conv_wgrad: alignment");
+        MI355_REQUIRE(s.H < 32000 && s.W < 32000, "conv_wgrad: H, W must be < 32000");
         WProb& d = L.p[i];
         d.in = (const unsigned short*)s.in;  d.dy = (const unsigned short*)s.out;
         d.N = s.N; d.H = s.H; d.W = s.W; d.C = s.C; d.P = s.P; d.Q = s.Q; d.sh = s.sh; d.sw = s.sw;
@@ -320,6 +375,7 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
     }
     if (ntaps == 0) return MI355_OK;
     L.dw = dw;
+    { const char* e = getenv("MI355_DBG"); if (e) L.dbg = atoi(e); }
     L.colsum = colsum;
     L.slab_stride = slab_stride;
     MI355_REQUIRE(slab_stride == 0 || chunks <= max_slabs, "conv_wgrad_slabs: %d slabs > workspace for %d", chunks, max_slabs);

@@ -23,6 +23,7 @@ for phase, steps in (('fwd', plan.fwd_steps), ('bwd', plan.bwd_steps)):
             continue
         L = ctypes.cast(args[0], ctypes.POINTER(ops_conv.ConvLaunch)).contents if False else args[0]._obj
         flops = 0.0
+        nbytes = 2.0 * L.K * L.T * L.prob[0].C * (1 if name == 'mi355_conv_gather' else 2)
         desc = []
         for i in range(L.nprob):
             p = L.prob[i]
@@ -32,6 +33,13 @@ for phase, steps in (('fwd', plan.fwd_steps), ('bwd', plan.bwd_steps)):
             else:
                 f = 2.0 * M * L.K * p.C * p.TR * p.TS
             flops += f
+            nbytes += 2.0 * p.N * p.H * p.W * p.C          # input / x
+            if name == 'mi355_conv_gather':
+                nbytes += M * L.K * (4.0 if L.out_f32 else 2.0)
+                if p.addend: nbytes += 2.0 * M * L.K / (4 ** p.add_shift)
+                if p.mask: nbytes += 2.0 * M * L.K
+            else:
+                nbytes += 2.0 * M * L.K
             desc.append('%dx%dx%d' % (p.N, p.P, p.Q))
         p0 = L.prob[0]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,13 +50,14 @@ for phase, steps in (('fwd', plan.fwd_steps), ('bwd', plan.bwd_steps)):
             fn(*args, s)
         e1.record(st); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 5 * 1e3
-        rows.append((phase, name[11:17], L.nprob, p0.C, L.K, p0.TR, p0.TS, p0.sh, '+'.join(desc[:2]), flops, us))
+        rows.append((phase, name[11:17], L.nprob, p0.C, L.K, p0.TR, p0.TS, p0.sh, '+'.join(desc[:2]), flops, us, max(nbytes / 5.0e6, flops / 1.2e9)))
 tot_f = sum(r[9] for r in rows); tot_t = sum(r[10] for r in rows)
 print('total %.1f GFLOP (padded channel counts) in %.2f ms = %.1f TFLOP/s' % (tot_f / 1e9, tot_t / 1e3, tot_f / tot_t / 1e6))
 agg = {}
 for r in rows:
     key = r[:9]
-    a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += r[9]; a[2] += r[10]
+    a = agg.setdefault(key, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += r[9]; a[2] += r[10]; a[3] += r[11]
 for key, a in sorted(agg.items(), key=lambda kv: -kv[1][2]):
-    print('%-3s %-7s np%d C%-4d K%-4d %dx%d s%d %-26s n=%-2d %8.1f us/launch %7.1f TF/s  %5.1f%% of time'
-          % (key + (a[0], a[2] / a[0], a[1] / a[2] / 1e6, 100 * a[2] / tot_t)))
+    print('%-3s %-7s np%d C%-4d K%-4d %dx%d s%d %-26s n=%-2d %8.1f us/launch %7.1f TF/s  %5.1f%% of time  floor %6.1f us  lost %7.1f us'
+          % (key + (a[0], a[2] / a[0], a[1] / a[2] / 1e6, 100 * a[2] / tot_t, a[3] / a[0], a[2] - a[3])))
+print('sum of floors (max(bytes / 5 TB/s, flops / 1.2 PF/s)): %.2f ms' % (sum(r[11] for r in rows) / 1e3))
