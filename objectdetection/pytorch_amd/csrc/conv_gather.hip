@@ -60,6 +60,170 @@ __device__ __forceinline__ float activate(float v, int act) {
     return v;
 }
 
+// Accumulators hold the TRANSPOSED tile: acc[i][j][r] = out[pixel i*16+fr][channel j*16+fq*4+r]
+// (weights are the MFMA A operand), so a lane owns 4 consecutive channels of one pixel and the
+// epilogue stages with 8/16-B LDS writes.  The bias is the accumulator's initial value.
+__device__ __forceinline__ void init_acc(f4v (&acc)[4][4], const LaunchDev& L, int n0, int wn, int fq) {
+    {
+        f4v b4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b4[j] = (f4v){0.f, 0.f, 0.f, 0.f};
+        if (L.bias) {                                  // uniform branch; 4 loads in flight together
+            if ((L.K & 3) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    b4[j] = *reinterpret_cast<const f4v*>(L.bias + min(n0 + wn * 64 + j * 16 + fq * 4, L.K - 4));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        b4[j][r] = L.bias[min(n0 + wn * 64 + j * 16 + fq * 4 + r, L.K - 1)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    b4[j][r] = (n0 + wn * 64 + j * 16 + fq * 4 + r) < L.K ? b4[j][r] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = b4[j];
+    }
+}
+
+// Epilogue through LDS: bias is already in the accumulators; addend / activation / ReLU-backward mask,
+// 16-B coalesced row stores.
+template <int WM>
+__device__ __forceinline__ void gather_epilogue(f4v (&acc)[4][4], const LaunchDev& L, const ProbDev& P,
+                                                unsigned char* smem, const long long* s_outoff,
+                                                const long long* s_addoff, int n0) {
+    constexpr int NTHREADS = WM * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int col = (tid & 15) * 8;
+    const int k0 = n0 + col;
+    const int nvalid = min(8, L.K - k0);
+    const bool full = nvalid == 8;
+    const bool mask_first = (L.flags & 1) != 0;
+    const bool fast = !L.out_f32 && !P.addend && (L.K & 7) == 0;
+    if (fast) {
+        // FAST: activation in registers, bf16 staging of the whole tile (one barrier), the read
+        // side is a 16-B copy (+ the ReLU-backward mask as a bit select).
+        unsigned short* st16 = reinterpret_cast<unsigned short*>(smem);
+        long long oo[8];
+        s8v mk[8];
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {       // mask reads first: latency hides under staging
+            const int row = pass * (NTHREADS / 16) + (tid >> 4);
+            oo[pass] = k0 < L.K ? s_outoff[row] : -1;
+            mk[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+            if (P.mask && oo[pass] >= 0) mk[pass] = *reinterpret_cast<const s8v*>(P.mask + oo[pass] + k0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s4v pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_rn(activate(acc[i][j][r], L.act));
+                *reinterpret_cast<s4v*>(st16 + (wm * 64 + i * 16 + fr) * EPI16_LD + wn * 64 + j * 16 + fq * 4) = pk;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            if (oo[pass] < 0) continue;
+            const int row = pass * (NTHREADS / 16) + (tid >> 4);
+            const s4v lo = *reinterpret_cast<const s4v*>(st16 + row * EPI16_LD + col);
+            const s4v hi = *reinterpret_cast<const s4v*>(st16 + row * EPI16_LD + col + 4);
+            s8v o = (s8v){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (P.mask) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)       // bf16 > 0  <=>  sign clear and not +-0
+                    o[e] = ((unsigned short)mk[pass][e] & 0x8000u) || !((unsigned short)mk[pass][e] & 0x7fffu) ? (short)0 : o[e];
+            }
+            *reinterpret_cast<s8v*>(reinterpret_cast<unsigned short*>(P.out) + oo[pass] + k0) = o;
+        }
+        return;
+    }
+    // GENERAL: fp32 staging in two 64-row halves (addend / fp32 output / ragged channel tails)
+    float* epi = reinterpret_cast<float*>(smem);
+    constexpr int PH = 64 / (NTHREADS / 16);           // read passes per 64-row slice
+    for (int half = 0; half < WM; ++half) {
+        long long oo[PH];
+        s8v mk[PH], ad[PH];
+#pragma unroll
+        for (int pass = 0; pass < PH; ++pass) {
+            const int row = half * 64 + pass * (NTHREADS / 16) + (tid >> 4);
+            oo[pass] = k0 < L.K ? s_outoff[row] : -1;
+            mk[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+            ad[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+            if (oo[pass] >= 0 && full) {
+                if (P.mask) mk[pass] = *reinterpret_cast<const s8v*>(P.mask + oo[pass] + k0);
+                if (P.addend) ad[pass] = *reinterpret_cast<const s8v*>(P.addend + s_addoff[row] + k0);
+            }
+        }
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<f4v*>(epi + (i * 16 + fr) * EPI_LD + wn * 64 + j * 16 + fq * 4) = acc[i][j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < PH; ++pass) {
+            if (oo[pass] < 0) continue;
+            const int hrow = pass * (NTHREADS / 16) + (tid >> 4);
+            const f4v v0 = *reinterpret_cast<const f4v*>(epi + hrow * EPI_LD + col);
+            const f4v v1 = *reinterpret_cast<const f4v*>(epi + hrow * EPI_LD + col + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (full) {
+                if (P.mask && mask_first) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((unsigned short)mk[pass][e]) > 0.0f ? v[e] : 0.0f;
+                }
+                if (P.addend) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((unsigned short)ad[pass][e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = activate(v[e], L.act);
+                if (P.mask && !mask_first) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((unsigned short)mk[pass][e]) > 0.0f ? v[e] : 0.0f;
+                }
+                if (L.out_f32) {
+                    float* op = reinterpret_cast<float*>(P.out) + oo[pass] + k0;
+                    *reinterpret_cast<f4v*>(op) = (f4v){v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f4v*>(op + 4) = (f4v){v[4], v[5], v[6], v[7]};
+                } else {
+                    s8v o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(v[e]);
+                    *reinterpret_cast<s8v*>(reinterpret_cast<unsigned short*>(P.out) + oo[pass] + k0) = o;
+                }
+            } else {                               // ragged channel tail (K % 8 != 0): scalar path
+                const int row = half * 64 + hrow;
+                const unsigned short* mp = P.mask ? P.mask + oo[pass] + k0 : nullptr;
+                const unsigned short* ap = P.addend ? P.addend + s_addoff[row] + k0 : nullptr;
+                for (int e = 0; e < nvalid; ++e) {
+                    float x = v[e];
+                    if (mp && mask_first) x = bf16_to_f32(mp[e]) > 0.0f ? x : 0.0f;
+                    if (ap) x += bf16_to_f32(ap[e]);
+                    x = activate(x, L.act);
+                    if (mp && !mask_first) x = bf16_to_f32(mp[e]) > 0.0f ? x : 0.0f;
+                    if (L.out_f32) (reinterpret_cast<float*>(P.out) + oo[pass] + k0)[e] = x;
+                    else (reinterpret_cast<unsigned short*>(P.out) + oo[pass] + k0)[e] = f32_to_bf16_rn(x);
+                }
+            }
+        }
+        if (half + 1 < WM) __syncthreads();
+    }
+}
+
 // WM = wave rows (each wave owns 64 x 64 outputs; 2 wave columns): tile = (WM*64) x 128, WM*128 threads.
 // <WM 2, STAGES 2>: 128x128, double-buffered k-loop, 64 KiB LDS, 2 blocks/CU.
 // <WM 2, STAGES 1>: one stage, 33 KiB LDS, 3-4 blocks/CU: short reductions (<= 2 k-steps) are HBM /
@@ -185,10 +349,6 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
     const int wm = wv >> 1, wn = wv & 1;
     const int fr = lane & 15, fq = lane >> 4;
     f4v acc[4][4];
-    // epilogue geometry
-    const int col = (tid & 15) * 8;
-    const int k0 = n0 + col;
-    const int nvalid = min(8, L.K - k0);
     // ds_read_b128 byte offsets of this lane's fragments inside a stage (row r, chunk c):
     //   r*128 + ((c ^ (r & 7)) << 4); r & 7 == fr & 7 for every 16-row tile.
     const int a_rd = (wm * 64 + fr) * 128;
@@ -216,36 +376,7 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
     };
     if (ksteps > 0) issue(0, 0);
     // (bias loads are issued behind the first stage's DMA so that both latencies overlap)
-    // Accumulators hold the TRANSPOSED tile: acc[i][j][r] = out[pixel i*16+fr][channel j*16+fq*4+r]
-    // (weights are the MFMA A operand), so a lane owns 4 consecutive channels of one pixel and
-    // the epilogue stages with 8/16-B LDS writes.  The bias is the accumulator's initial value.
-    {
-        f4v b4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b4[j] = (f4v){0.f, 0.f, 0.f, 0.f};
-        if (L.bias) {                                  // uniform branch; 4 loads in flight together
-            if ((L.K & 3) == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    b4[j] = *reinterpret_cast<const f4v*>(L.bias + min(n0 + wn * 64 + j * 16 + fq * 4, L.K - 4));
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        b4[j][r] = L.bias[min(n0 + wn * 64 + j * 16 + fq * 4 + r, L.K - 1)];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    b4[j][r] = (n0 + wn * 64 + j * 16 + fq * 4 + r) < L.K ? b4[j][r] : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = b4[j];
-    }
+    init_acc(acc, L, n0, wn, fq);
     if (STAGES == 3) {
         // three-stage ring: stage ks is read while ks+1 and ks+2 are in flight.  Per thread a stage is
         // 4 + NB DMA instructions; `vmcnt(4 + NB)` therefore retires stage ks and leaves ks+1 flying.
@@ -280,123 +411,184 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
         }
     }
 
-    // ---- epilogue
-    const bool full = nvalid == 8;
-    const bool mask_first = (L.flags & 1) != 0;
-    const bool fast = !L.out_f32 && !P.addend && (L.K & 7) == 0;
-    if (fast) {
-        // FAST: activation in registers, bf16 staging of the whole tile (one barrier), the read
-        // side is a 16-B copy (+ the ReLU-backward mask as a bit select).
-        unsigned short* st16 = reinterpret_cast<unsigned short*>(smem);
-        long long oo[8];
-        s8v mk[8];
+    gather_epilogue<WM>(acc, L, P, smem, s_outoff, s_addoff, n0);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// ROW3: 3x3 / stride 1 / "same" convs with C % 64 == 0 (tower and FPN convs, bottleneck conv2 and
+// their data gradients).  The three taps of one kernel row read the SAME input rows shifted by one
+// pixel, so the activation tile of a (kernel row, 64-channel block) is staged ONCE, two rows longer,
+// and the column taps are ds_reads at shifted row addresses (lanes whose column leaves the image read
+// a zero row).  Per k-step this is 4 weight + 4.25/3 activation LDS-DMA pieces per thread instead of
+// 8 (WM = 2), and a third of the gather-address arithmetic: the generic kernel is bound by exactly
+// those (vector-memory issue, not MFMA).  Staged row j of a group holds the input pixel below
+// "virtual output pixel" m0 - 1 + j; output row i and column tap s read staged row i + s.
+template <int WM>
+__global__ __launch_bounds__(WM * 128, 2) void conv_gather_row3_kernel(const LaunchDev L) {
+    constexpr int NTHREADS = WM * 128, BM = WM * 64;
+    constexpr int AROWS = BM + 8;                      // staged rows (BM + 2 used), 8-row DMA granules
+    constexpr int A_BYTES = AROWS * BK * 2;
+    constexpr int Z_ROW = (AROWS - 1) * 128;           // staged rows >= BM + 2 are never in range: zeros
+    constexpr int B_OFF = 2 * A_BYTES;
+    constexpr int B_BYTES = BN * BK * 2;
+    constexpr int NB = 1024 / NTHREADS;
+    constexpr int ROWSTEP = NTHREADS / 8;
+    constexpr int NA = (AROWS + ROWSTEP - 1) / ROWSTEP;   // A DMA passes (the last one partial)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ long long s_outoff[BM];
+    __shared__ long long s_addoff[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m_tile = tile / L.n_tiles, n_tile = tile - m_tile * L.n_tiles;
+    int pi = 0;
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {       // mask reads first: latency hides under staging
-            const int row = pass * (NTHREADS / 16) + (tid >> 4);
-            oo[pass] = k0 < L.K ? s_outoff[row] : -1;
-            mk[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
-            if (P.mask && oo[pass] >= 0) mk[pass] = *reinterpret_cast<const s8v*>(P.mask + oo[pass] + k0);
+    for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
+        if (i < L.nprob && m_tile >= L.p[i].tile_begin) pi = i;
+    const ProbDev P = L.p[pi];
+    const int m0 = (m_tile - P.tile_begin) * BM;
+    const int n0 = n_tile * BN;
+    const int PQ = P.P * P.Q;
+
+    if (tid < BM) {
+        const int m = m0 + tid;
+        long long oo = -1, ao = -1;
+        if (m < P.M) {
+            const int n = (int)fdiv((unsigned)m, P.dPQ), rem = m - n * PQ;
+            const int p = (int)fdiv((unsigned)rem, P.dQ), q = rem - p * P.Q;
+            oo = n * P.out_sN + (long long)(p * P.out_mh + P.out_oh) * P.out_sH +
+                 (long long)(q * P.out_mw + P.out_ow) * P.out_sW;
+            ao = n * P.add_sN + (long long)(p >> P.add_shift) * P.add_sH +
+                 (long long)(q >> P.add_shift) * P.add_sW;
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s4v pk;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_rn(activate(acc[i][j][r], L.act));
-                *reinterpret_cast<s4v*>(st16 + (wm * 64 + i * 16 + fr) * EPI16_LD + wn * 64 + j * 16 + fq * 4) = pk;
-            }
-        __syncthreads();
-#pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
-            if (oo[pass] < 0) continue;
-            const int row = pass * (NTHREADS / 16) + (tid >> 4);
-            const s4v lo = *reinterpret_cast<const s4v*>(st16 + row * EPI16_LD + col);
-            const s4v hi = *reinterpret_cast<const s4v*>(st16 + row * EPI16_LD + col + 4);
-            s8v o = (s8v){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if (P.mask) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)       // bf16 > 0  <=>  sign clear and not +-0
-                    o[e] = ((unsigned short)mk[pass][e] & 0x8000u) || !((unsigned short)mk[pass][e] & 0x7fffu) ? (short)0 : o[e];
-            }
-            *reinterpret_cast<s8v*>(reinterpret_cast<unsigned short*>(P.out) + oo[pass] + k0) = o;
-        }
-        return;
+        s_outoff[tid] = oo;
+        s_addoff[tid] = ao;
     }
-    // GENERAL: fp32 staging in two 64-row halves (addend / fp32 output / ragged channel tails)
-    float* epi = reinterpret_cast<float*>(smem);
-    constexpr int PH = 64 / (NTHREADS / 16);           // read passes per 64-row slice
-    for (int half = 0; half < WM; ++half) {
-        long long oo[PH];
-        s8v mk[PH], ad[PH];
+
+    // ---- staging geometry
+    const int slot = tid & 7;
+    const int kc = slot ^ ((tid >> 3) & 7);            // (row & 7) is the same for every pass
+    int a_base[NA], a_p[NA];
+    unsigned b_rowoff[NB];
+    const int wrow = L.T * P.C;
 #pragma unroll
-        for (int pass = 0; pass < PH; ++pass) {
-            const int row = half * 64 + pass * (NTHREADS / 16) + (tid >> 4);
-            oo[pass] = k0 < L.K ? s_outoff[row] : -1;
-            mk[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
-            ad[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
-            if (oo[pass] >= 0 && full) {
-                if (P.mask) mk[pass] = *reinterpret_cast<const s8v*>(P.mask + oo[pass] + k0);
-                if (P.addend) ad[pass] = *reinterpret_cast<const s8v*>(P.addend + s_addoff[row] + k0);
-            }
+    for (int i = 0; i < NA; ++i) {
+        const int j = (tid >> 3) + ROWSTEP * i;
+        const int v = m0 - 1 + j;                      // virtual output pixel of staged row j
+        a_p[i] = -0x40000000;
+        a_base[i] = 0;
+        if (v >= 0 && v < P.M && j < BM + 2) {
+            const int n = (int)fdiv((unsigned)v, P.dPQ), rem = v - n * PQ;
+            const int p = (int)fdiv((unsigned)rem, P.dQ), q = rem - p * P.Q;
+            a_p[i] = p;
+            a_base[i] = n * (int)P.in_sN + (p * P.W + q) * P.C;
         }
-        if (wm == half) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<f4v*>(epi + (i * 16 + fr) * EPI_LD + wn * 64 + j * 16 + fq * 4) = acc[i][j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int pass = 0; pass < PH; ++pass) {
-            if (oo[pass] < 0) continue;
-            const int hrow = pass * (NTHREADS / 16) + (tid >> 4);
-            const f4v v0 = *reinterpret_cast<const f4v*>(epi + hrow * EPI_LD + col);
-            const f4v v1 = *reinterpret_cast<const f4v*>(epi + hrow * EPI_LD + col + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            if (full) {
-                if (P.mask && mask_first) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((unsigned short)mk[pass][e]) > 0.0f ? v[e] : 0.0f;
-                }
-                if (P.addend) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((unsigned short)ad[pass][e]);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = activate(v[e], L.act);
-                if (P.mask && !mask_first) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((unsigned short)mk[pass][e]) > 0.0f ? v[e] : 0.0f;
-                }
-                if (L.out_f32) {
-                    float* op = reinterpret_cast<float*>(P.out) + oo[pass] + k0;
-                    *reinterpret_cast<f4v*>(op) = (f4v){v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f4v*>(op + 4) = (f4v){v[4], v[5], v[6], v[7]};
-                } else {
-                    s8v o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(v[e]);
-                    *reinterpret_cast<s8v*>(reinterpret_cast<unsigned short*>(P.out) + oo[pass] + k0) = o;
-                }
-            } else {                               // ragged channel tail (K % 8 != 0): scalar path
-                const int row = half * 64 + hrow;
-                const unsigned short* mp = P.mask ? P.mask + oo[pass] + k0 : nullptr;
-                const unsigned short* ap = P.addend ? P.addend + s_addoff[row] + k0 : nullptr;
-                for (int e = 0; e < nvalid; ++e) {
-                    float x = v[e];
-                    if (mp && mask_first) x = bf16_to_f32(mp[e]) > 0.0f ? x : 0.0f;
-                    if (ap) x += bf16_to_f32(ap[e]);
-                    x = activate(x, L.act);
-                    if (mp && !mask_first) x = bf16_to_f32(mp[e]) > 0.0f ? x : 0.0f;
-                    if (L.out_f32) (reinterpret_cast<float*>(P.out) + oo[pass] + k0)[e] = x;
-                    else (reinterpret_cast<unsigned short*>(P.out) + oo[pass] + k0)[e] = f32_to_bf16_rn(x);
-                }
-            }
-        }
-        if (half + 1 < WM) __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int nn = n0 + (tid >> 3) + ROWSTEP * i;
+        b_rowoff[i] = nn < L.K ? (unsigned)(nn * wrow) * 2u : OOB_OFFSET;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(P.in, (unsigned)P.in_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(L.w, (unsigned)L.w_bytes);
+    const int nchunks = P.C / BK;
+    const int ngroups = 3 * nchunks;                   // (kernel row, channel block)
+    const int nsteps = 3 * ngroups;                    // x column tap
+
+    // groups and steps are issued in order: carried counters, no division
+    int ga_r = 0, ga_c = 0;                            // next A group
+    auto issue_a = [&](int buf) {
+        unsigned char* sa = smem + buf * A_BYTES;
+        const int dh = P.dh0 + ga_r;
+        const int delta = dh * P.W * P.C + ga_c + kc * 8;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (i * ROWSTEP + (wv * 8) < AROWS) {      // wave-uniform: the last pass is partial
+                const bool ok = (unsigned)(a_p[i] + dh) < (unsigned)P.H;
+                const unsigned off = ok ? (unsigned)(a_base[i] + delta) * 2u : OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (LDS_PTR(void))(sa + (i * NTHREADS + wv * 64) * 16),
+                                                         16, off, 0, 0, 0);
+            }
+        }
+        ga_c += BK;
+        if (ga_c == P.C) { ga_c = 0; ++ga_r; }
+    };
+    int gb_r = 0, gb_c = 0, gb_s = 0;                  // next B step
+    auto issue_b = [&](int buf) {
+        unsigned char* sb = smem + B_OFF + buf * B_BYTES;
+        const unsigned b_delta = (unsigned)(((P.r0 + gb_r * P.rs) * P.S + (P.s0 + gb_s * P.ss)) * P.C + gb_c + kc * 8) * 2u;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const unsigned off = b_rowoff[i] != OOB_OFFSET ? b_rowoff[i] + b_delta : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (LDS_PTR(void))(sb + (i * NTHREADS + wv * 64) * 16),
+                                                     16, off, 0, 0, 0);
+        }
+        if (++gb_s == 3) {
+            gb_s = 0;
+            gb_c += BK;
+            if (gb_c == P.C) { gb_c = 0; ++gb_r; }
+        }
+    };
+
+    const int wm = wv >> 1, wn = wv & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    f4v acc[4][4];
+    // fragment addresses: output row i = wm*64 + t*16 + fr reads staged row i + s (s = 0, 1, 2);
+    // lanes whose column q + s - 1 leaves [0, Q) read the zero row instead.
+    int a_rd[4][3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = wm * 64 + t * 16 + fr;
+        const int m = min(m0 + i, P.M - 1);
+        const int n = (int)fdiv((unsigned)m, P.dPQ), rem = m - n * PQ;
+        const int p = (int)fdiv((unsigned)rem, P.dQ), q = rem - p * P.Q;
+        a_rd[t][0] = q > 0 ? i * 128 : Z_ROW;
+        a_rd[t][1] = (i + 1) * 128;
+        a_rd[t][2] = q < P.Q - 1 ? (i + 2) * 128 : Z_ROW;
+    }
+    int a_sw[3][2];                                    // (chunk ^ (staged row & 7)) << 4, per tap and k-sub
+#pragma unroll
+    for (int sft = 0; sft < 3; ++sft) {
+        a_sw[sft][0] = (fq ^ ((fr + sft) & 7)) << 4;
+        a_sw[sft][1] = ((4 + fq) ^ ((fr + sft) & 7)) << 4;
+    }
+    const int b_rd = (wn * 64 + fr) * 128;
+    const int b_sw0 = (fq ^ (fr & 7)) << 4, b_sw1 = ((4 + fq) ^ (fr & 7)) << 4;
+
+    issue_a(0);
+    issue_b(0);
+    init_acc(acc, L, n0, wn, fq);
+
+    int abuf = 0, step = 0;
+    for (int group = 0; group < ngroups; ++group) {
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft) {            // static: fragment addresses stay in registers
+            __syncthreads();                           // every DMA issued so far has landed (vmcnt(0))
+            if (sft == 0 && group + 1 < ngroups) issue_a(abuf ^ 1);   // last read two groups ago
+            if (step + 1 < nsteps) issue_b((step + 1) & 1);
+            const unsigned char* sa = smem + abuf * A_BYTES;
+            const unsigned char* sb = smem + B_OFF + (step & 1) * B_BYTES;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                s8v af[4], bf[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    af[t] = *reinterpret_cast<const s8v*>(sa + a_rd[t][sft] + a_sw[sft][sub]);
+                    bf[t] = *reinterpret_cast<const s8v*>(sb + b_rd + t * 16 * 128 + (sub ? b_sw1 : b_sw0));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+            ++step;
+        }
+        abuf ^= 1;
+    }
+    __syncthreads();
+    gather_epilogue<WM>(acc, L, P, smem, s_outoff, s_addoff, n0);
 }
 
 }  // namespace
@@ -427,9 +619,21 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
         const char* e = getenv("MI355_GATHER_BIG");
         return e ? atoi(e) : 256;
     }();
-    const bool big = !flat && max_ksteps >= 6 && big_min_grid > 0 &&
+    static const int row3_mode = [] {
+        const char* e = getenv("MI355_ROW3");
+        return e ? atoi(e) : 2;
+    }();
+    bool row3 = !flat && row3_mode > 0;                // 3x3 / stride 1 / same: column taps share a staging
+    for (int i = 0; i < in.nprob && row3; ++i) {
+        const Mi355ConvProblem& s = in.prob[i];
+        // (data gradients walk the taps downwards: dw0 = +1, dws = -1; canonicalised below)
+        row3 = s.TR == 3 && s.TS == 3 && s.sh == 1 && s.sw == 1 && (s.dhs == 1 || s.dhs == -1) &&
+               ((s.dws == 1 && s.dw0 == -1) || (s.dws == -1 && s.dw0 == 1)) && s.Q == s.W;
+    }
+    const bool row3_big = row3 && row3_mode == 4;
+    const bool big = !row3 && !flat && max_ksteps >= 6 && big_min_grid > 0 &&
                      big_tiles * cdiv(in.K, BN) >= big_min_grid;
-    const int BM = big ? 256 : 128;
+    const int BM = (big || row3_big) ? 256 : 128;
     for (int i = 0; i < in.nprob; ++i) {
         const Mi355ConvProblem& s = in.prob[i];
         MI355_REQUIRE(s.in && s.out, "conv_gather: problem %d null in/out", i);
@@ -455,6 +659,10 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
         d.dPQ = make_fastdiv((unsigned)(s.P * s.Q));
         d.dQ = make_fastdiv((unsigned)s.Q);
         d.in_bytes = (int)in_bytes;
+        if (row3) {                                    // ascending taps: tap i' = 2 - i
+            if (d.dhs < 0) { d.dh0 += 2 * d.dhs; d.dhs = 1; d.r0 += 2 * d.rs; d.rs = -d.rs; }
+            if (d.dws < 0) { d.dw0 += 2 * d.dws; d.dws = 1; d.s0 += 2 * d.ss; d.ss = -d.ss; }
+        }
         d.tile_begin = tiles;
         tiles += (int)cdiv(d.M, BM);
     }
@@ -470,16 +678,22 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
     const long long grid = (long long)tiles * L.n_tiles;
     MI355_REQUIRE(grid > 0 && grid < 0x7fffffffLL, "conv_gather: grid");
     constexpr int STAGE2 = (128 + BN) * BK * 2, STAGE3 = (256 + BN) * BK * 2;
+    constexpr int ROW3_LDS2 = 2 * (128 + 8) * BK * 2 + 2 * BN * BK * 2, ROW3_LDS4 = 2 * (256 + 8) * BK * 2 + 2 * BN * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);
         (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);
         (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
+        (void)hipFuncSetAttribute((const void*)conv_gather_row3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ROW3_LDS2);
+        (void)hipFuncSetAttribute((const void*)conv_gather_row3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ROW3_LDS4);
         attr_set = true;
     }
     const dim3 g((unsigned)grid);
     hipStream_t st = (hipStream_t)stream;
-    if (big) {
+    if (row3) {
+        if (row3_big) hipLaunchKernelGGL((conv_gather_row3_kernel<4>), g, dim3(512), ROW3_LDS4, st, L);
+        else          hipLaunchKernelGGL((conv_gather_row3_kernel<2>), g, dim3(256), ROW3_LDS2, st, L);
+    } else if (big) {
         hipLaunchKernelGGL((conv_gather_kernel<false, 3, 4>), g, dim3(512), 3 * STAGE3, st, L);
     } else if (single) {
         if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
