@@ -125,7 +125,7 @@ typedef struct Mi355LayerDesc {
     float eps;
     int32_t atomic;          /* grads: != 0 when another descriptor writes the same dW / dbias
                                 (weights shared across pyramid levels): use atomics */
-    int32_t reserved;
+    int32_t nslabs;          /* grads: G / colsum hold this many split-K slabs (0 or 1: a single buffer) */
     const float* gamma;      /* frozen BN (all four NULL when the layer has no BN) */
     const float* beta;
     const float* mean;
@@ -141,6 +141,8 @@ typedef struct Mi355LayerDesc {
     float* dgamma;           /* (+=) or NULL */
     float* dbeta;            /* (+=): BN beta, or the conv bias of a BN-less layer, or NULL */
     float* dconv_bias;       /* (+=) or NULL */
+    int64_t slab_stride;     /* grads: floats between consecutive G slabs (colsum slabs are Kpad apart);
+                                the slabs are summed in index order: bit-reproducible gradients */
 } Mi355LayerDesc;
 int mi355_prep_weights_table(const Mi355LayerDesc* d_table, int nlayers, int nblocks, void* stream);
 int mi355_param_grads_table(const Mi355LayerDesc* d_table, int nlayers, int nblocks, void* stream);

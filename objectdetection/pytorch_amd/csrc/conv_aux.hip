@@ -424,14 +424,26 @@ __global__ __launch_bounds__(256) void param_grads_table_kernel(const Mi355Layer
     const float sck = d.gamma ? d.gamma[k] / sqrtf(d.var[k] + d.eps) : 1.0f;
     float dot = 0.0f;
     const int total = T * d.Cpad;
-    for (int i = tid; i < total; i += 256) {
-        const int t = i / d.Cpad, c = i - t * d.Cpad;
-        if (c >= d.C) continue;
+    // 16-B slab reads (Cpad % 8 == 0, rows and slabs 16-B aligned), slabs summed in index order
+    for (int i4 = tid * 4; i4 < total; i4 += 1024) {
+        const float4* gp = reinterpret_cast<const float4*>(d.G + (long long)k * total + i4);
+        float4 g4 = gp[0];
+        for (int sl = 1; sl < d.nslabs; ++sl) {
+            const float4 v = gp[sl * (d.slab_stride >> 2)];
+            g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
+        }
+        const float ge[4] = {g4.x, g4.y, g4.z, g4.w};
+        const int t = i4 / d.Cpad, c0 = i4 - t * d.Cpad;
         const int r = t / d.S, s = t - r * d.S;
-        const float gv = d.G[(long long)k * total + i];
-        const long long wo = k * d.sk + c * d.sc + r * d.sr + s * d.ss;
-        if (d.dgamma) dot += d.w[wo] * gv;
-        if (d.atomic) atomicAdd(d.dW + wo, gv * sck); else d.dW[wo] += gv * sck;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + e;
+            if (c >= d.C) continue;
+            const float gv = ge[e];
+            const long long wo = k * d.sk + c * d.sc + r * d.sr + s * d.ss;
+            if (d.dgamma) dot += d.w[wo] * gv;
+            if (d.atomic) atomicAdd(d.dW + wo, gv * sck); else d.dW[wo] += gv * sck;
+        }
     }
     if (d.dgamma || d.dbeta || d.dconv_bias) {
         __shared__ float red[4];
@@ -440,7 +452,8 @@ __global__ __launch_bounds__(256) void param_grads_table_kernel(const Mi355Layer
         if ((tid & 63) == 0) red[tid >> 6] = dot;
         __syncthreads();
         if (tid == 0) {
-            const float cs = d.colsum[k];
+            float cs = d.colsum[k];
+            for (int sl = 1; sl < d.nslabs; ++sl) cs += d.colsum[(long long)sl * d.Kpad + k];
             if (d.dgamma) {
                 const float invstd = 1.0f / sqrtf(d.var[k] + d.eps);
                 const float mu = d.mean[k] - (d.conv_bias ? d.conv_bias[k] : 0.0f);

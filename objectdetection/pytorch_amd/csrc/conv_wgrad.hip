@@ -239,7 +239,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
             v += __shfl_xor(v, 16, 64);                // the 4 lane groups hold disjoint pixels
             v += __shfl_xor(v, 32, 64);
             const int k = k0 + wk * 64 + t * 16 + (lane & 15);
-            if (lane < 16 && k < L.K) atomicAdd(L.colsum + k, v);
+            if (lane < 16 && k < L.K) {
+                if (L.slab_stride > 0) L.colsum[(long long)chunk * L.K + k] = v;   // slab mode: [chunk][K]
+                else atomicAdd(L.colsum + k, v);
+            }
         }
     }
     // ---- epilogue: LDS-staged, one 256-B contiguous atomic row segment per wave instruction

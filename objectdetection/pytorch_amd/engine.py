@@ -42,6 +42,7 @@ class LayerSpec(object):
         # filled by the plan
         self.w_fwd = self.w_dgr = self.scale = self.shift = None
         self.G = self.colsum = None
+        self.nslabs = 0
         self.direct = False        # wgrad writes straight into the parameter-gradient arena
 
     @property
@@ -67,7 +68,14 @@ class RetinaPlan(object):
         self.prep_steps, self.fwd_steps, self.bwd_steps, self.pgrad_steps = [], [], [], []
         self.bufs = []
         self.fwd_launches = []         # (spec, [(n, p, q) per problem]) for FLOP accounting
-        self.deterministic = os.environ.get('MI355_DETERMINISTIC', '0') == '1'
+        # weight-gradient reduction over pixel chunks: 'slabs' (default; plain stores into per-chunk slabs,
+        # summed in fixed order by the parameter-gradient table launch: bit-reproducible) or 'atomic'
+        # (fp32 atomics straight into the gradient).  MI355_DETERMINISTIC=1 forces 'slabs'.
+        self.wgrad_mode = os.environ.get('MI355_WGRAD', 'slabs')
+        if os.environ.get('MI355_DETERMINISTIC', '0') == '1':
+            self.wgrad_mode = 'slabs'
+        assert self.wgrad_mode in ('slabs', 'atomic')
+        self.deterministic = self.wgrad_mode == 'slabs'
         self.last_arena = 0
         self._meta()
         if H % self.input_multiple or W % self.input_multiple:
@@ -184,8 +192,8 @@ class RetinaPlan(object):
                 s.scale = self.bnbuf[bo:bo + s.K]
                 s.shift = self.bnbuf[bo + s.K:bo + 2 * s.K]
                 bo += 2 * s.K
-            s.direct = (s.bn is None and s.Cpad == s.C and s.Kpad == s.K)
-            if not s.direct:
+            s.direct = (not self.deterministic and s.bn is None and s.Cpad == s.C and s.Kpad == s.K)
+            if not s.direct and not self.deterministic:
                 scratch += s.Kpad * s.T * s.Cpad + s.Kpad
         self.scratch = self.new((max(scratch, 1),), torch.float32, zero=True)
         self._carve_grads(0)
@@ -207,7 +215,7 @@ class RetinaPlan(object):
                 s.G = self.grad_arenas[arena][off:off + w.numel()]
                 boff = self.grad_offsets[id(s.conv.bias)]
                 s.colsum = self.grad_arenas[arena][boff:boff + s.K]
-            else:
+            elif not self.deterministic:              # (slab mode: _wgrad allocates the slabs of each layer)
                 n = s.Kpad * s.T * s.Cpad
                 s.G = self.scratch[so:so + n]
                 s.colsum = self.scratch[so + n:so + n + s.Kpad]
@@ -231,6 +239,8 @@ class RetinaPlan(object):
         d.w_dgr = s.w_dgr.data_ptr() if s.w_dgr is not None else 0
         if arena is not None:
             d.G, d.colsum = s.G.data_ptr(), s.colsum.data_ptr()
+            if self.deterministic:
+                d.nslabs, d.slab_stride = s.nslabs, s.Kpad * s.T * s.Cpad
             d.dW = self.grad_view(w, arena).data_ptr()
             if bn is not None:
                 d.dgamma = self.grad_view(bn.weight, arena).data_ptr()
@@ -263,13 +273,12 @@ class RetinaPlan(object):
         self._step(lst, 'mi355_conv_gather', ctypes.byref(L))
         self.keep.append(L)
 
-    WG_WS_FLOATS = 48 * 1024 * 1024        # shared split-K slab workspace (192 MiB fp32)
-
     def _wgrad(self, problems, spec, rows, colsum=True):
-        """Weight gradient.  MI355_DETERMINISTIC=1 selects deterministic split-K: every pixel chunk
-        stores its partial dW tile in a slab of the shared workspace (plain stores), then one
-        fixed-order reduce adds the slabs into the gradient (or the raw-G scratch of BN-folded
-        layers): bit-reproducible weight gradients."""
+        """Weight gradient, split over pixel chunks.  'slabs': every chunk stores its partial dW tile
+        (and dy column sums) with plain stores into its own slab of the layer's workspace; the
+        parameter-gradient table launch sums the slabs in index order while it folds the frozen BN
+        (plain stores run ~5x the fp32-atomic rate on gfx950: tools/probe_atomics.hip) and the
+        gradients are bit-reproducible.  'atomic': fp32 atomics straight into the gradient."""
         L = ConvLaunch()
         for j, pr in enumerate(problems):
             L.prob[j] = pr
@@ -281,21 +290,16 @@ class RetinaPlan(object):
         self.keep.append(L)
         spec._wgrad_launch = L
         if not self.deterministic:
-            # default: fp32 atomics straight into the gradient (measured 3 % faster end to end than
-            # the slab path at R50 512^2 bs16; last-bit run-to-run differences in parameter grads)
             self._step(self.bwd_steps, 'mi355_conv_wgrad_colsum', ctypes.byref(L), ptr(spec.G),
                        ptr(spec.colsum if colsum else None), c_int(split))
             return
-        if getattr(self, 'wg_ws', None) is None:
-            self.wg_ws = self.new((self.WG_WS_FLOATS,), torch.float32)
         nslabs = sum(-(-(p.N * p.P * p.Q) // split) for p in problems)
-        while nslabs * slab > self.WG_WS_FLOATS:               # cap by the workspace
-            split *= 2
-            nslabs = sum(-(-(p.N * p.P * p.Q) // split) for p in problems)
-        self._step(self.bwd_steps, 'mi355_conv_wgrad_slabs', ctypes.byref(L), ptr(self.wg_ws), c_i64(slab),
+        if spec.G is None or spec.nslabs != nslabs:
+            spec.nslabs = nslabs
+            spec.G = self.new((nslabs, slab), torch.float32)           # every element is written each step
+            spec.colsum = self.new((nslabs, spec.Kpad), torch.float32, zero=True)
+        self._step(self.bwd_steps, 'mi355_conv_wgrad_slabs', ctypes.byref(L), ptr(spec.G), c_i64(slab),
                    c_int(nslabs), ptr(spec.colsum if colsum else None), c_int(split))
-        self._step(self.bwd_steps, 'mi355_slab_reduce', ptr(self.wg_ws), c_int(nslabs), c_i64(slab), c_i64(slab),
-                   ptr(spec.G), c_int(1))
 
     def conv(self, spec, x, act=ACT_NONE, addend=None, add_shift=0):
         N, H, W, C = x.shape
