@@ -20,12 +20,16 @@ using namespace mi355;
 
 namespace {
 
-constexpr int TK = 128, TC = 128, RM = 64, NTHREADS = 256;
-constexpr int STAGE_BYTES = (TK + TC) * RM * 2;           // 32 KiB
+constexpr int TK = 128, TC = 128, RM = 64;
 constexpr int EPI_LD = TC + 4;
-constexpr int TAB_STEPS = 8, TAB_ROWS = TAB_STEPS * RM;   // pixel-row table: 512 rows x 16 B behind the stages
-constexpr int TAB_OFF = 2 * STAGE_BYTES;
-constexpr int LDS_BYTES = (TAB_OFF + TAB_ROWS * 16 > TK * EPI_LD * 4) ? TAB_OFF + TAB_ROWS * 16 : TK * EPI_LD * 4;
+constexpr int TAB_ROWS = 512;                             // pixel-row table: 512 rows x 16 B behind the stages
+// NG = wave groups per block.  Each group of 4 waves owns 64 of the stage's 64*NG pixel rows and the
+// full 128x128 tile; the groups' partial tiles are added through LDS before the block writes ONE
+// partial tile, i.e. half the split-K slabs (or atomics) at the same number of resident waves.
+constexpr int stage_bytes(int ng) { return (TK + TC) * RM * ng * 2; }           // 32 KiB per group
+constexpr int lds_bytes(int ng) {
+    return (2 * stage_bytes(ng) + TAB_ROWS * 16 > TK * EPI_LD * 4) ? 2 * stage_bytes(ng) + TAB_ROWS * 16 : TK * EPI_LD * 4;
+}
 
 struct WProb {
     const unsigned short* in;
@@ -63,9 +67,13 @@ __device__ __forceinline__ void lds_wait() {
     __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs behind the wait (guide §5.4 rule 18)
 }
 
-template <bool FLAT>
-__global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L) {
+template <bool FLAT, int NG>
+__global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L) {
+    constexpr int NTHREADS = 256 * NG, RMS = RM * NG;   // rows per stage
+    constexpr int STAGE_BYTES = stage_bytes(NG), TAB_OFF = 2 * STAGE_BYTES, TAB_STEPS = TAB_ROWS / RMS;
+    constexpr int ROWSTEP = NTHREADS / 16;              // rows covered by one DMA instruction of the block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float s_cs[TK];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     // block -> (chunk, tap, k_tile, c_tile); tiles of one chunk are adjacent so that the
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
     int4* tab = reinterpret_cast<int4*>(smem + TAB_OFF);
     auto fill = [&](int step0) {
         for (int e = tid; e < TAB_ROWS; e += NTHREADS) {
-            const int m = m_begin + step0 * RM + e;
+            const int m = m_begin + step0 * RMS + e;
             int4 t = make_int4(0, 0x7fff0000, -1, 0);          // row beyond the chunk: never in range
             if (m < m_end) {
                 const unsigned n = fdiv((unsigned)m, P.dPQ);
@@ -140,19 +148,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
     const int tapoff = (dh * P.W + dw) * P.C + cx;
     auto issue = [&](int step, int buf) {
         unsigned char* sy = smem + buf * STAGE_BYTES;
-        unsigned char* sx = sy + TK * RM * 2;
+        unsigned char* sx = sy + TK * RMS * 2;
         int4 t[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] = tab[(step & (TAB_STEPS - 1)) * RM + srow + 16 * i];   // before any DMA
+        for (int i = 0; i < 4; ++i) t[i] = tab[(step & (TAB_STEPS - 1)) * RMS + srow + ROWSTEP * i];   // before any DMA
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ih = (t[i].y >> 16) + dh, iw = (t[i].y & 0xffff) + dw;
             const unsigned offy = (ky_ok && t[i].z >= 0) ? (unsigned)(t[i].z + ky) * 2u : OOB_OFFSET;
             const unsigned offx = (cx_ok && (unsigned)ih < (unsigned)P.H && (unsigned)iw < (unsigned)P.W)
                                       ? (unsigned)(t[i].x + tapoff) * 2u : OOB_OFFSET;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (LDS_PTR(void))(sy + (i * 256 + wv * 64) * 16),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (LDS_PTR(void))(sy + (i * NTHREADS + wv * 64) * 16),
                                                      16, offy, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_PTR(void))(sx + (i * 256 + wv * 64) * 16),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_PTR(void))(sx + (i * NTHREADS + wv * 64) * 16),
                                                      16, offx, 0, 0, 0);
         }
     };
@@ -164,26 +172,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
         for (int j = 0; j < 4; ++j) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
 
     // transposed-read addressing (16-lane group g, lane 4q+p): row 8g + q (+4), columns 4p..4p+3
-    const int wk = wv >> 1, wc = wv & 1;
+    const int grp = wv >> 2;                           // pixel-row group of this wave
+    const int wk = (wv >> 1) & 1, wc = wv & 1;
     const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int f = (q4 | ((g & 1) << 2)) << 1;
     const int row_lo = 8 * g + q4;
     // logical 16-B chunk of (tile t of this wave, p4): 8*wk + 2t + (p4 >> 1) for dy, 8*wc + ... for x
     const int half8 = (p4 & 1) * 8;
-    constexpr int XOFF = TK * RM * 2;                  // x tile behind the dy tile of a stage
+    constexpr int XOFF = TK * RMS * 2;                 // x tile behind the dy tile of a stage
     const unsigned lds0 = (unsigned)(uintptr_t)(LDS_PTR(void))smem;
     unsigned ady[4], adx[4];                           // byte offsets inside a stage (rows 0..31: +0 / +4 rows)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        ady[t] = row_lo * 256 + ((8 * wk + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
-        adx[t] = row_lo * 256 + ((8 * wc + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
+        ady[t] = (grp * RM + row_lo) * 256 + ((8 * wk + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
+        adx[t] = (grp * RM + row_lo) * 256 + ((8 * wc + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
     }
 
     // column sums of dy (bias / BN-beta gradient): only the blocks owning (tap 0, c-tile 0) and
     // only their wc == 0 waves (the other column-waves hold the same dy fragments)
     const bool do_colsum = L.colsum != nullptr && c_tile == 0 && tap == 0 && wc == 0;
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
-    const int nsteps = (m_end - m_begin + RM - 1) / RM;
+    const int nsteps = (m_end - m_begin + RMS - 1) / RMS;
     fill(0);
     __syncthreads();
     if (nsteps > 0) issue(0, 0);
@@ -232,30 +241,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
         __syncthreads();
     }
 
+    // ---- epilogue: the groups' partial tiles (and column sums) are added through LDS in group order,
+    //      then written as 256-B contiguous row segments (plain slab stores, or fp32 atomics)
+    float* epi = reinterpret_cast<float*>(smem);
+    const int fr = lane & 15, fq = lane >> 4;
+    float cs_v[4] = {0.f, 0.f, 0.f, 0.f};
     if (do_colsum) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float v = csum[t];
             v += __shfl_xor(v, 16, 64);                // the 4 lane groups hold disjoint pixels
             v += __shfl_xor(v, 32, 64);
+            cs_v[t] = v;
+            if (NG > 1 && grp == 1 && lane < 16) s_cs[wk * 64 + t * 16 + lane] = v;
+        }
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    epi[(wk * 64 + i * 16 + fq * 4 + r) * EPI_LD + wc * 64 + j * 16 + fr] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (NG > 1) {
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        epi[(wk * 64 + i * 16 + fq * 4 + r) * EPI_LD + wc * 64 + j * 16 + fr] += acc[i][j][r];
+        }
+        __syncthreads();
+    }
+    if (do_colsum && grp == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
             const int k = k0 + wk * 64 + t * 16 + (lane & 15);
             if (lane < 16 && k < L.K) {
+                const float v = cs_v[t] + (NG > 1 ? s_cs[wk * 64 + t * 16 + lane] : 0.0f);
                 if (L.slab_stride > 0) L.colsum[(long long)chunk * L.K + k] = v;   // slab mode: [chunk][K]
                 else atomicAdd(L.colsum + k, v);
             }
         }
     }
-    // ---- epilogue: LDS-staged, one 256-B contiguous atomic row segment per wave instruction
-    float* epi = reinterpret_cast<float*>(smem);
-    const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                epi[(wk * 64 + i * 16 + fq * 4 + r) * EPI_LD + wc * 64 + j * 16 + fr] = acc[i][j][r];
-    __syncthreads();
     const long long wrow = (long long)L.T * P.C;
     long long coff[2];
 #pragma unroll
@@ -272,7 +305,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv_wgrad_kernel(const WLaunch L
             if (c0 + c < P.C) coff[h] = (long long)((P.r0 + ti * P.rs) * P.S + (P.s0 + tj * P.ss)) * P.C + c0 + c;
         }
     }
-    for (int rr = wv; rr < TK; rr += 4) {
+    for (int rr = wv; rr < TK; rr += 4 * NG) {
         const int k = k0 + rr;
         if (k >= L.K) break;
 #pragma unroll
@@ -347,6 +380,13 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
     MI355_REQUIRE(in.nprob >= 1 && in.nprob <= MI355_CONV_MAX_PROBLEMS, "conv_wgrad: nprob");
     MI355_REQUIRE(in.K > 0 && in.K % 8 == 0 && in.T > 0, "conv_wgrad: K must be a positive multiple of 8");
     MI355_REQUIRE(split_rows > 0 && split_rows % RM == 0, "conv_wgrad: split_rows must be a multiple of 64");
+    // MI355_WG_GROUPS=2: two wave groups per block when the chunk is a multiple of 128 rows (half the
+    // slabs; measured slower end to end than two independent four-wave blocks per CU, so off by default)
+    static const int max_groups = [] {
+        const char* e = getenv("MI355_WG_GROUPS");
+        return e ? atoi(e) : 1;
+    }();
+    const bool two = max_groups >= 2 && split_rows % (2 * RM) == 0;
     WLaunch L;
     memset(&L, 0, sizeof(L));
     const int C = in.prob[0].C;
@@ -391,15 +431,20 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
     MI355_REQUIRE(grid > 0 && grid < 0x7fffffffLL, "conv_wgrad: grid");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2));
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2));
         attr_set = true;
     }
-    if (flat)
-        hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES,
-                           (hipStream_t)stream, L);
-    else
-        hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3((unsigned)grid), dim3(NTHREADS), LDS_BYTES,
-                           (hipStream_t)stream, L);
+    const dim3 g((unsigned)grid);
+    hipStream_t st = (hipStream_t)stream;
+    if (two) {
+        if (flat) hipLaunchKernelGGL((conv_wgrad_kernel<true, 2>), g, dim3(512), lds_bytes(2), st, L);
+        else      hipLaunchKernelGGL((conv_wgrad_kernel<false, 2>), g, dim3(512), lds_bytes(2), st, L);
+    } else {
+        if (flat) hipLaunchKernelGGL((conv_wgrad_kernel<true, 1>), g, dim3(256), lds_bytes(1), st, L);
+        else      hipLaunchKernelGGL((conv_wgrad_kernel<false, 1>), g, dim3(256), lds_bytes(1), st, L);
+    }
     return check_launch("conv_wgrad_kernel");
 }

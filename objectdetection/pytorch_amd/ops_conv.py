@@ -143,12 +143,14 @@ def wgrad_tiles(kpad, cpad, taps):
     return kt * (-(-taps * cpad // 128)) if cpad < 128 else kt * taps * (-(-cpad // 128))
 
 
-def pick_split_rows(total_rows, tiles_per_chunk, target_blocks=512, min_rows=512):
-    """Rows of the pixel reduction per block: ~2 blocks per CU, but never so few rows that the
-    fp32-atomic epilogue (64 KiB per block) outweighs the MFMA work."""
+def pick_split_rows(total_rows, tiles_per_chunk, target_blocks=512, min_rows=512, granule=64):
+    """Rows of the pixel reduction per block: ~2 four-wave blocks per CU, but never so few rows that
+    the partial-tile epilogue (64 KiB per block) outweighs the MFMA work.  (Measured on R50 512^2
+    bs16: 512 blocks / 512 rows beats 256..1024 blocks; one eight-wave block per CU with two row
+    groups, MI355_WG_GROUPS=2 + granule 128, halves the slabs but runs 2 % slower end to end.)"""
     chunks = max(1, target_blocks // max(1, tiles_per_chunk))
     rows = -(-total_rows // chunks)
-    rows = max(min_rows, -(-rows // 64) * 64)
+    rows = max(min_rows, -(-rows // granule) * granule)
     return rows
 
 
