@@ -58,6 +58,12 @@ typedef struct Mi355ConvLaunch {
 
 /* out = act( gatherconv(in, weight) + bias + addend ) * (mask > 0) for every problem. */
 int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream);
+/* Same result for launches with few output tiles and a long reduction (P6 = conv3x3 s2 over C5,
+ * retinanet.py:64; the 16x16 stage): the taps x channels reduction is cut into `ksplit` ranges that run
+ * as separate blocks and store fp32 partial tiles into slab `split` of `ws` (ksplit * sum over problems
+ * of N*P*Q*K floats, no initialisation needed); one pass then sums the slabs in index order
+ * (bit-reproducible), applies bias / addend / activation / mask and writes `out`. */
+int mi355_conv_gather_splitk(const Mi355ConvLaunch* launch, int ksplit, float* ws, void* stream);
 
 /* Weight gradient of the same gather conv, grouped over problems that share the weight:
  *   dw[k][t][c] += sum_m dy[m][k] * in[m @ tap t][c]        (fp32 atomics; zero dw first)

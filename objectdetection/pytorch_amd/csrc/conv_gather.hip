@@ -52,6 +52,8 @@ struct LaunchDev {
     const unsigned short* w;
     const float* bias;
     int nprob, K, T, act, out_f32, n_tiles, w_bytes, flags;
+    int ksplit, tiles_total;      // split-K: blockIdx = split * tiles_total + tile
+    long long split_stride;       // floats between the partial-output slabs of consecutive splits
 };
 
 __device__ __forceinline__ float activate(float v, int act) {
@@ -242,7 +244,8 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
     __shared__ long long s_addoff[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int split = L.ksplit > 1 ? blockIdx.x / L.tiles_total : 0;
+    const int tile = L.ksplit > 1 ? blockIdx.x - split * L.tiles_total : xcd_swizzle(blockIdx.x, gridDim.x);
     const int m_tile = tile / L.n_tiles, n_tile = tile - m_tile * L.n_tiles;
 
     // ---- select the problem of this tile (scalar selects over the by-value descriptors)
@@ -250,7 +253,8 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
 #pragma unroll
     for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
         if (i < L.nprob && m_tile >= L.p[i].tile_begin) pi = i;
-    const ProbDev P = L.p[pi];                           // one block copy out of the kernarg segment
+    ProbDev P = L.p[pi];                                 // one block copy out of the kernarg segment
+    if (L.ksplit > 1) P.out = reinterpret_cast<float*>(P.out) + split * L.split_stride;
     const int m0 = (m_tile - P.tile_begin) * BM;
     const int n0 = n_tile * BN;
     const int PQ = P.P * P.Q;
@@ -300,18 +304,27 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
 
     const int ntaps = P.TR * P.TS;
     const int cpt = P.C >> 3;                          // 16-B chunks per tap
-    const int ksteps = FLAT ? (ntaps * cpt + 7) / 8 : ntaps * (P.C / BK);
+    const int ksteps_all = FLAT ? (ntaps * cpt + 7) / 8 : ntaps * (P.C / BK);
+    // split-K: this block reduces k-steps [ks_begin, ks_begin + ksteps) into slab `split` of the workspace
+    const int ks_begin = L.ksplit > 1 ? (int)((long long)ksteps_all * split / L.ksplit) : 0;
+    const int ksteps = (L.ksplit > 1 ? (int)((long long)ksteps_all * (split + 1) / L.ksplit) : ksteps_all) - ks_begin;
 
     // k-steps are issued strictly in order, so the (tap row, tap column, channel block) of the next
     // stage is carried as wave-uniform counters instead of being decoded from ks by division.
     int nx_ti = 0, nx_tj = 0, nx_c = 0;
+    if (!FLAT && ks_begin > 0) {
+        const int cb = P.C / BK, tap = ks_begin / cb;
+        nx_c = (ks_begin - tap * cb) * BK;
+        nx_ti = tap / P.TS;
+        nx_tj = tap - nx_ti * P.TS;
+    }
     auto issue = [&](int ks, int buf) {
         unsigned char* sa = smem + buf * STAGE_BYTES;
         unsigned char* sb = sa + A_BYTES;
         int ti, tj, c0;
         bool tap_ok = true;
         if (FLAT) {
-            const int J = ks * 8 + kc;
+            const int J = (ks_begin + ks) * 8 + kc;
             const int tap = J / cpt;
             c0 = (J - tap * cpt) * 8;
             ti = tap / P.TS;
@@ -591,11 +604,52 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_row3_kernel(const Lau
     gather_epilogue<WM>(acc, L, P, smem, s_outoff, s_addoff, n0);
 }
 
+// Split-K finish: out = mask( act( sum_s ws[s] + bias (+ addend) ) ) with the generic epilogue's ordering;
+// the partial slabs are summed in index order (bit-reproducible).
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, int ksplit, long long split_stride,
+                                                            const ProbDev P, const float* __restrict__ bias,
+                                                            int K, int act, int out_f32, int mask_first) {
+    const int kc8 = (K + 7) >> 3;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)P.M * kc8) return;
+    const int m = (int)(idx / kc8), k0 = (int)(idx - (long long)m * kc8) * 8;
+    const int PQ = P.P * P.Q;
+    const int n = (int)fdiv((unsigned)m, P.dPQ), rem = m - n * PQ;
+    const int p = (int)fdiv((unsigned)rem, P.dQ), q = rem - p * P.Q;
+    const long long oo = n * P.out_sN + (long long)(p * P.out_mh + P.out_oh) * P.out_sH +
+                         (long long)(q * P.out_mw + P.out_ow) * P.out_sW;
+    const long long ao = n * P.add_sN + (long long)(p >> P.add_shift) * P.add_sH + (long long)(q >> P.add_shift) * P.add_sW;
+    const float* w = ws + (long long)m * K + k0;
+    const int nv = min(8, K - k0);
+    for (int e = 0; e < nv; ++e) {
+        float x = w[e];
+        for (int sp = 1; sp < ksplit; ++sp) x += w[sp * split_stride + e];
+        if (bias) x += bias[k0 + e];
+        const float mk = P.mask ? bf16_to_f32(P.mask[oo + k0 + e]) : 1.0f;
+        if (P.mask && mask_first) x = mk > 0.0f ? x : 0.0f;
+        if (P.addend) x += bf16_to_f32(P.addend[ao + k0 + e]);
+        x = activate(x, act);
+        if (P.mask && !mask_first) x = mk > 0.0f ? x : 0.0f;
+        if (out_f32) reinterpret_cast<float*>(P.out)[oo + k0 + e] = x;
+        else reinterpret_cast<unsigned short*>(P.out)[oo + k0 + e] = f32_to_bf16_rn(x);
+    }
+}
+
 }  // namespace
+
+static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void* stream);
 
 extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
     MI355_REQUIRE(launch, "conv_gather: null launch");
-    const Mi355ConvLaunch& in = *launch;
+    return gather_launch(*launch, 1, nullptr, stream);
+}
+
+extern "C" int mi355_conv_gather_splitk(const Mi355ConvLaunch* launch, int ksplit, float* ws, void* stream) {
+    MI355_REQUIRE(launch && ws && ksplit >= 1, "conv_gather_splitk: bad arguments");
+    return gather_launch(*launch, ksplit, ws, stream);
+}
+
+static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void* stream) {
     MI355_REQUIRE(in.nprob >= 1 && in.nprob <= MI355_CONV_MAX_PROBLEMS, "conv_gather: nprob %d", in.nprob);
     MI355_REQUIRE(in.K > 0 && in.weight && in.T > 0, "conv_gather: bad K/weight/T");
     LaunchDev L;
@@ -614,7 +668,7 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
         if (ks > max_ksteps) max_ksteps = ks;
         big_tiles += cdiv((long long)in.prob[i].N * in.prob[i].P * in.prob[i].Q, 256);
     }
-    const bool single = max_ksteps <= 2;
+    const bool single = max_ksteps <= 2 && ksplit <= 1;
     static const int big_min_grid = [] {
         const char* e = getenv("MI355_GATHER_BIG");
         return e ? atoi(e) : 256;
@@ -623,7 +677,8 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
         const char* e = getenv("MI355_ROW3");
         return e ? atoi(e) : 2;
     }();
-    bool row3 = !flat && row3_mode > 0;                // 3x3 / stride 1 / same: column taps share a staging
+    const bool splitk = ksplit > 1;
+    bool row3 = !flat && row3_mode > 0 && !splitk;     // 3x3 / stride 1 / same: column taps share a staging
     for (int i = 0; i < in.nprob && row3; ++i) {
         const Mi355ConvProblem& s = in.prob[i];
         // (data gradients walk the taps downwards: dw0 = +1, dws = -1; canonicalised below)
@@ -631,7 +686,7 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
                ((s.dws == 1 && s.dw0 == -1) || (s.dws == -1 && s.dw0 == 1)) && s.Q == s.W;
     }
     const bool row3_big = row3 && row3_mode == 4;
-    const bool big = !row3 && !flat && max_ksteps >= 6 && big_min_grid > 0 &&
+    const bool big = !row3 && !splitk && !flat && max_ksteps >= 6 && big_min_grid > 0 &&
                      big_tiles * cdiv(in.K, BN) >= big_min_grid;
     const int BM = (big || row3_big) ? 256 : 128;
     for (int i = 0; i < in.nprob; ++i) {
@@ -675,8 +730,31 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
     { const char* e = getenv("MI355_DBG"); if (e) L.flags |= atoi(e); }
     L.n_tiles = (int)cdiv(in.K, BN);
     L.w_bytes = (int)w_bytes;
-    const long long grid = (long long)tiles * L.n_tiles;
+    long long grid = (long long)tiles * L.n_tiles;
     MI355_REQUIRE(grid > 0 && grid < 0x7fffffffLL, "conv_gather: grid");
+    L.ksplit = 1;
+    L.tiles_total = (int)grid;
+    ProbDev fin[MI355_CONV_MAX_PROBLEMS];
+    if (splitk) {
+        // partial tiles go to slab `split` of the fp32 workspace [ksplit][sum M][K] (plain stores); bias,
+        // addend, activation and mask are applied by the finish kernel
+        MI355_REQUIRE(max_ksteps >= ksplit, "conv_gather_splitk: ksplit %d > %d k-steps", ksplit, max_ksteps);
+        long long off = 0;
+        for (int i = 0; i < in.nprob; ++i) {
+            ProbDev& d = L.p[i];
+            fin[i] = d;
+            d.out = ws + off;
+            d.out_sN = (long long)d.P * d.Q * in.K; d.out_sH = (long long)d.Q * in.K; d.out_sW = in.K;
+            d.out_mh = d.out_mw = 1; d.out_oh = d.out_ow = 0;
+            d.addend = nullptr; d.mask = nullptr;
+            off += (long long)d.M * in.K;
+        }
+        L.bias = nullptr; L.act = 0; L.out_f32 = 1;
+        L.ksplit = ksplit;
+        L.split_stride = off;
+        grid *= ksplit;
+        MI355_REQUIRE(grid < 0x7fffffffLL, "conv_gather_splitk: grid");
+    }
     constexpr int STAGE2 = (128 + BN) * BK * 2, STAGE3 = (256 + BN) * BK * 2;
     constexpr int ROW3_LDS2 = 2 * (128 + 8) * BK * 2 + 2 * BN * BK * 2, ROW3_LDS4 = 2 * (256 + 8) * BK * 2 + 2 * BN * BK * 2;
     static bool attr_set = false;
@@ -701,6 +779,15 @@ extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
     } else {
         if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 2, 2>), g, dim3(256), 2 * STAGE2, st, L);
         else      hipLaunchKernelGGL((conv_gather_kernel<false, 2, 2>), g, dim3(256), 2 * STAGE2, st, L);
+    }
+    if (splitk) {
+        long long off = 0;
+        for (int i = 0; i < in.nprob; ++i) {
+            const long long n = (long long)fin[i].M * ((in.K + 7) / 8);
+            hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, ws + off, ksplit,
+                               L.split_stride, fin[i], in.bias, in.K, in.act, in.out_f32, in.flags & 1);
+            off += (long long)fin[i].M * in.K;
+        }
     }
     return check_launch("conv_gather_kernel");
 }

@@ -270,8 +270,29 @@ class RetinaPlan(object):
             L.prob[j] = pr
         L.nprob, L.K, L.weight, L.T = len(problems), K, weight.data_ptr(), T
         L.act, L.bias, L.out_f32, L.flags = act, (0 if bias is None else bias.data_ptr()), int(out_f32), flags
-        self._step(lst, 'mi355_conv_gather', ctypes.byref(L))
         self.keep.append(L)
+        ksplit = self._pick_ksplit(problems, K, T)
+        if ksplit > 1:
+            need = ksplit * sum(p.N * p.P * p.Q for p in problems) * K
+            ws = self.new((need,), torch.float32)                 # partial-tile slabs of this launch
+            self._step(lst, 'mi355_conv_gather_splitk', ctypes.byref(L), c_int(ksplit), ptr(ws))
+        else:
+            self._step(lst, 'mi355_conv_gather', ctypes.byref(L))
+
+    @staticmethod
+    def _pick_ksplit(problems, K, T):
+        """Split the taps x channels reduction over blocks when the output has too few 128x128 tiles
+        to cover the 256 CUs and the reduction is long (P6/P7 convs, the 16x16 stage at batch 16)."""
+        if os.environ.get('MI355_SPLITK', '1') == '0':
+            return 1
+        C = problems[0].C
+        if C % 64:
+            return 1
+        tiles = sum(-(-(p.N * p.P * p.Q) // 128) for p in problems) * (-(-K // 128))
+        ksteps = min(p.TR * p.TS for p in problems) * (C // 64)
+        if tiles > 160 or ksteps < 16:
+            return 1
+        return max(1, min(ksteps // 8, 384 // tiles))
 
     def _wgrad(self, problems, spec, rows, colsum=True):
         """Weight gradient, split over pixel chunks.  'slabs': every chunk stores its partial dW tile

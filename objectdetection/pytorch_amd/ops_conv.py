@@ -117,7 +117,7 @@ def dgrad_problems(dy, dx_ptr, H, W, Cin, R, S, stride, pad, addend=None, mask=N
     return probs
 
 
-def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE, out_f32=False):
+def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE, out_f32=False, ksplit=1):
     for i in range(0, len(problems), MAX_PROBLEMS):
         chunk = problems[i:i + MAX_PROBLEMS]
         L = ConvLaunch()
@@ -125,7 +125,12 @@ def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE
             L.prob[j] = pr
         L.nprob, L.K, L.weight, L.T = len(chunk), K, weight.data_ptr(), T
         L.act, L.bias, L.out_f32 = act, _dp(bias), 1 if out_f32 else 0
-        call('mi355_conv_gather', ctypes.byref(L), stream_of(stream_tensor))
+        if ksplit > 1:      # reduction split over blocks, partial tiles in a scratch workspace
+            ws = torch.empty(ksplit * sum(p.N * p.P * p.Q for p in chunk) * K, dtype=torch.float32,
+                             device=stream_tensor.device)
+            call('mi355_conv_gather_splitk', ctypes.byref(L), c_int(ksplit), ptr(ws), stream_of(stream_tensor))
+        else:
+            call('mi355_conv_gather', ctypes.byref(L), stream_of(stream_tensor))
 
 
 def launch_wgrad(problems, K, T, dw, split_rows, stream_tensor, colsum=None):
@@ -156,13 +161,13 @@ def pick_split_rows(total_rows, tiles_per_chunk, target_blocks=512, min_rows=512
 
 # ---------------------------------------------------------------- simple single-problem helpers
 def conv_fwd(x, w_fwd, K, R, S, stride, pad, bias=None, act=ACT_NONE, addend=None, add_shift=0,
-             out_f32=False):
+             out_f32=False, ksplit=1):
     require_gpu(x, w_fwd)
     N, H, W, C = x.shape
     P, Q = out_hw(H, W, R, stride, pad)[0], out_hw(H, W, S, stride, pad)[1]
     out = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     pr = fwd_problem(x, out.data_ptr(), R, S, stride, pad, K=K, addend=addend, add_shift=add_shift)
-    launch_gather([pr], w_fwd, K, R * S, x, bias=bias, act=act, out_f32=out_f32)
+    launch_gather([pr], w_fwd, K, R * S, x, bias=bias, act=act, out_f32=out_f32, ksplit=ksplit)
     return out
 
 

@@ -76,6 +76,31 @@ def test_conv_fwd(dev, case):
     _close(out.permute(0, 3, 1, 2), torch.sigmoid(ref), 2e-3)
 
 
+@pytest.mark.parametrize('case,ksplit', [((1, 4, 4, 2048, 256, 3, 2, 1), 16), ((2, 9, 7, 512, 192, 3, 1, 1), 3),
+                                         ((2, 6, 5, 1024, 36, 1, 1, 0), 4)])
+def test_conv_fwd_splitk(dev, case, ksplit):
+    """Few output tiles, long reduction (P6, the deepest stage): reduction split over blocks with
+    per-split slabs summed in order by the finish pass == the unsplit launch (fp32 summation order
+    aside) and bit-reproducible run to run."""
+    from objectdetection.pytorch_amd import ops_conv
+    N, H, W, C, K, R, stride, pad = case
+    x = _mk((N, C, H, W), 1)
+    w = _mk((K, C, R, R), 2, scale=(2.0 / (C * R * R)) ** 0.5)
+    b = _mk((K,), 3).float()
+    res = _mk((N, K, (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1), 4)
+    ref = F.relu(F.conv2d(x, w, b, stride, pad) + res)
+    _, w_fwd, _ = _shadow(w, dev)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    rh = res.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    outs = [ops_conv.conv_fwd(xh, w_fwd, K, R, R, stride, pad, bias=b.to(dev), act=ops_conv.ACT_RELU, addend=rh,
+                              out_f32=True, ksplit=ksplit) for _ in range(2)]
+    _close(outs[0].permute(0, 3, 1, 2), ref, 2e-3)
+    assert torch.equal(outs[0], outs[1])
+    out16 = ops_conv.conv_fwd(xh, w_fwd, K, R, R, stride, pad, bias=b.to(dev), act=ops_conv.ACT_RELU, addend=rh,
+                              ksplit=ksplit)
+    _close(out16.permute(0, 3, 1, 2), ref, 1e-2)
+
+
 def test_conv_fwd_bn_fold_addend_relu(dev):
     """conv -> frozen BN -> (+ residual) -> ReLU, utils_resnet.py:60-80."""
     from objectdetection.pytorch_amd import ops_conv

@@ -19,22 +19,22 @@ st = torch.cuda.current_stream()
 rows = []
 for phase, steps in (('fwd', plan.fwd_steps), ('bwd', plan.bwd_steps)):
     for fn, args, name in steps:
-        if name not in ('mi355_conv_gather', 'mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum'):
+        if name not in ('mi355_conv_gather', 'mi355_conv_gather_splitk', 'mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum'):
             continue
         L = ctypes.cast(args[0], ctypes.POINTER(ops_conv.ConvLaunch)).contents if False else args[0]._obj
         flops = 0.0
-        nbytes = 2.0 * L.K * L.T * L.prob[0].C * (1 if name == 'mi355_conv_gather' else 2)
+        nbytes = 2.0 * L.K * L.T * L.prob[0].C * (1 if name.startswith('mi355_conv_gather') else 2)
         desc = []
         for i in range(L.nprob):
             p = L.prob[i]
             M = p.N * p.P * p.Q
-            if name == 'mi355_conv_gather':
+            if name.startswith('mi355_conv_gather'):
                 f = 2.0 * M * L.K * p.C * p.TR * p.TS
             else:
                 f = 2.0 * M * L.K * p.C * p.TR * p.TS
             flops += f
             nbytes += 2.0 * p.N * p.H * p.W * p.C          # input / x
-            if name == 'mi355_conv_gather':
+            if name.startswith('mi355_conv_gather'):
                 nbytes += M * L.K * (4.0 if L.out_f32 else 2.0)
                 if p.addend: nbytes += 2.0 * M * L.K / (4 ** p.add_shift)
                 if p.mask: nbytes += 2.0 * M * L.K
@@ -50,7 +50,7 @@ for phase, steps in (('fwd', plan.fwd_steps), ('bwd', plan.bwd_steps)):
             fn(*args, s)
         e1.record(st); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 5 * 1e3
-        rows.append((phase, name[11:17], L.nprob, p0.C, L.K, p0.TR, p0.TS, p0.sh, '+'.join(desc[:2]), flops, us, max(nbytes / 5.0e6, flops / 1.2e9)))
+        rows.append((phase, 'gath_sk' if name.endswith('splitk') else name[11:17], L.nprob, p0.C, L.K, p0.TR, p0.TS, p0.sh, '+'.join(desc[:2]), flops, us, max(nbytes / 5.0e6, flops / 1.2e9)))
 tot_f = sum(r[9] for r in rows); tot_t = sum(r[10] for r in rows)
 print('total %.1f GFLOP (padded channel counts) in %.2f ms = %.1f TFLOP/s' % (tot_f / 1e9, tot_t / 1e3, tot_f / tot_t / 1e6))
 agg = {}
