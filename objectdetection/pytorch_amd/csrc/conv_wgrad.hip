@@ -31,6 +31,8 @@ constexpr int lds_bytes(int ng) {
     return (2 * stage_bytes(ng) + TAB_ROWS * 16 > TK * EPI_LD * 4) ? 2 * stage_bytes(ng) + TAB_ROWS * 16 : TK * EPI_LD * 4;
 }
 
+constexpr int MAX_SORTED = 64;
+
 struct WProb {
     const unsigned short* in;
     const unsigned short* dy;
@@ -49,6 +51,11 @@ struct WLaunch {
     float* colsum;
     long long slab_stride;      // > 0: plain stores into slab `chunk` (dw + chunk*slab_stride), reduced later
     int nprob, K, T, k_tiles, c_tiles, ntaps, split_rows, dbg;
+    // grouped launches: chunks sorted by length (longest first), so that the short chunks of the small
+    // pyramid levels fill the tail of the launch instead of opening a second round of full-length blocks
+    int nsorted;                                // 0: chunk -> problem by chunk_begin (single problem)
+    unsigned char ch_prob[MAX_SORTED];
+    int ch_mbegin[MAX_SORTED];
 };
 
 // Transposed LDS read as opaque inline asm.  hipcc orders a visible LDS read behind EVERY pending
@@ -85,10 +92,19 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
     const int chunk = b;
 
     WProb P = L.p[0];
+    int m_begin;
+    if (L.nsorted > 0) {
+        const int pi = L.ch_prob[chunk];
 #pragma unroll
-    for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
-        if (i < L.nprob && chunk >= L.p[i].chunk_begin) P = L.p[i];
-    const int m_begin = (chunk - P.chunk_begin) * L.split_rows;
+        for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
+            if (i == pi) P = L.p[i];
+        m_begin = L.ch_mbegin[chunk];
+    } else {
+#pragma unroll
+        for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
+            if (i < L.nprob && chunk >= L.p[i].chunk_begin) P = L.p[i];
+        m_begin = (chunk - P.chunk_begin) * L.split_rows;
+    }
     const int m_end = min(P.M, m_begin + L.split_rows);
     const int k0 = k_tile * TK, c0 = c_tile * TC;
 
@@ -417,6 +433,23 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
         chunks += (int)cdiv(M, split_rows);
     }
     if (ntaps == 0) return MI355_OK;
+    if (in.nprob > 1 && chunks <= MAX_SORTED) {
+        int n = 0, rows[MAX_SORTED];
+        for (int i = 0; i < in.nprob; ++i)
+            for (int m = 0; m < L.p[i].M; m += split_rows) {
+                rows[n] = L.p[i].M - m < split_rows ? L.p[i].M - m : split_rows;
+                L.ch_prob[n] = (unsigned char)i;
+                L.ch_mbegin[n] = m;
+                ++n;
+            }
+        for (int a = 1; a < n; ++a)                      // stable insertion sort, longest first
+            for (int b = a; b > 0 && rows[b] > rows[b - 1]; --b) {
+                const int r = rows[b]; rows[b] = rows[b - 1]; rows[b - 1] = r;
+                const unsigned char pp = L.ch_prob[b]; L.ch_prob[b] = L.ch_prob[b - 1]; L.ch_prob[b - 1] = pp;
+                const int mb = L.ch_mbegin[b]; L.ch_mbegin[b] = L.ch_mbegin[b - 1]; L.ch_mbegin[b - 1] = mb;
+            }
+        L.nsorted = n;
+    }
     L.dw = dw;
     { const char* e = getenv("MI355_DBG"); if (e) L.dbg = atoi(e); }
     L.colsum = colsum;
