@@ -105,11 +105,47 @@ def conv_flops(plan):
     return fwd, fwd + dgrad + fwd     # (forward, training = fwd + dgrad + wgrad)
 
 
+CONV_STEPS = ('mi355_conv_gather', 'mi355_conv_gather_splitk', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_slabs')
+
+
+def conv_bytes(plan):
+    """Algorithmic HBM bytes of the conv launches of one step, unfused minimum per launch: every operand
+    read once, every result written once (bf16 activations, bf16 weight shadows, fp32 dW slabs)."""
+    total = 0.0
+    for fn, args, name in plan.fwd_steps + plan.bwd_steps:
+        if name not in CONV_STEPS:
+            continue
+        L = args[0]._obj
+        gather = name.startswith('mi355_conv_gather')
+        total += 2.0 * L.K * L.T * L.prob[0].C * (1 if gather else 2)      # weights / one dW tile set (fp32 = 2 x 2 B)
+        for i in range(L.nprob):
+            p = L.prob[i]
+            M = p.N * p.P * p.Q
+            total += 2.0 * p.N * p.H * p.W * p.C
+            if gather:
+                total += M * L.K * (4.0 if L.out_f32 else 2.0)
+                total += (2.0 * M * L.K / (4 ** p.add_shift)) if p.addend else 0.0
+                total += 2.0 * M * L.K if p.mask else 0.0
+            else:
+                total += 2.0 * M * L.K
+    return total
+
+
+def measured_traffic(args):
+    """HBM-side bytes per step of the conv kernels from the committed PMC passes (tools/collect_traffic.py;
+    FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950); only for the workload the
+    passes were taken on."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if not (args.arch == 'retinanet' and args.depth == 50 and args.size == 512 and args.batch == 16 and os.path.exists(path)):
+        return None, None
+    t = json.load(open(path))
+    return t['conv_kernels_bytes_per_step'], 'profiles/r01_pmc_traffic.json'
+
+
 def time_conv_kernels(plan, iters):
     """HIP-event time of ONLY the MFMA conv launches of one step (forward gather convs,
     backward gather convs = dgrad, wgrad), replayed back-to-back on the launch stream."""
-    names = ('mi355_conv_gather', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_slabs', 'mi355_slab_reduce')
-    steps = [s for s in plan.fwd_steps + plan.bwd_steps if s[2] in names]
+    steps = [s for s in plan.fwd_steps + plan.bwd_steps if s[2] in CONV_STEPS]
     st = torch.cuda.current_stream()
     plan.grad_arenas[0].zero_()
     plan._run(steps, st.cuda_stream)
@@ -239,9 +275,12 @@ def main():
         fwd_f, train_f = conv_flops(plan)
         conv_ms, nlaunch = time_conv_kernels(plan, 5)
         ach = train_f / (conv_ms * 1e-3) / 1e12
+        traffic, src = measured_traffic(args)
         out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-                           'kernel': 'conv_gather_kernel + conv_wgrad_kernel (%d launches/step)' % nlaunch,
+                           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                           'traffic_note': 'HBM-side bytes of the conv kernels per step (PMC, %s)' % src if src else None,
+                           'algorithmic_bytes_per_step': round(conv_bytes(plan)),
+                           'kernel': 'conv_gather(+row3, split-K) + conv_wgrad kernels (%d launches/step)' % nlaunch,
                            'algorithmic_gflop_per_image': round(train_f / B / 1e9, 2),
                            'conv_ms_per_step': round(conv_ms, 3)}
     if rank == 0 and not args.no_cpu_baseline and world == 1 and args.arch == 'retinanet':

@@ -88,6 +88,8 @@ class _TrainStep(torch.autograd.Function):
 
 
 class RetinaNet(nn.Module):
+    _plan_class = engine.RetinaPlan
+
     def __init__(self, num_classes, block, layers, iou_threshold=0.5, **kwargs):
         self.inplanes = 64
         super(RetinaNet, self).__init__()
@@ -119,6 +121,9 @@ class RetinaNet(nn.Module):
         self.regressBoxes = BBoxTransform()
         self.clipBoxes = ClipBoxes()
         self.focalLoss = losses.FocalLoss()
+        self._finish_init()
+
+    def _finish_init(self):
         for m in self.modules():                    # retinanet.py:232-238
             if isinstance(m, nn.Conv2d):
                 n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
@@ -179,7 +184,7 @@ class RetinaNet(nn.Module):
         key = (img.shape[0], img.shape[2], img.shape[3], img.device.index)
         plan = self._plans.get(key)
         if plan is None or plan.stale():
-            plan = engine.RetinaPlan(self, img.shape[0], img.shape[2], img.shape[3], img.device)
+            plan = self._plan_class(self, img.shape[0], img.shape[2], img.shape[3], img.device)
             self._plans = {key: plan}             # one live plan: buffers are sized for one shape
         return plan
 
@@ -248,6 +253,131 @@ def retinanet101(num_classes, pretrained=False, **kwargs):
 def retinanet152(num_classes, pretrained=False, **kwargs):
     _no_fetch(pretrained)
     return RetinaNet(num_classes, Bottleneck, [3, 8, 36, 3], **kwargs)
+
+
+
+# ---------------------------------------------------------------------------------------------
+# RetinaNetTiny (retinanet.py:447-679) and RetinaNetP45P6 (retinanet.py:682-922): three pyramid levels
+
+class PyramidFeaturesTiny(_PlanOnly):
+    def __init__(self, C2_size, C3_size, feature_size=256):
+        super(PyramidFeaturesTiny, self).__init__()
+        self.convert_onnx = False
+        self.pyramid_sizes = None
+        self.P3_1 = nn.Conv2d(C3_size, feature_size, kernel_size=1, stride=1, padding=0)
+        self.P3_upsampled = nn.Upsample(scale_factor=2, mode='nearest')
+        self.P3_2 = nn.Conv2d(feature_size, feature_size, kernel_size=3, stride=1, padding=1)
+        self.P2_1 = nn.Conv2d(C2_size, feature_size, kernel_size=1, stride=1, padding=0)
+        self.P2_2 = nn.Conv2d(feature_size, feature_size, kernel_size=3, stride=1, padding=1)
+        self.P4 = nn.Conv2d(C3_size, feature_size, kernel_size=3, stride=2, padding=1)
+
+
+class PyramidFeaturesP45P6(_PlanOnly):
+    def __init__(self, C4_size, C5_size, feature_size=256):
+        super(PyramidFeaturesP45P6, self).__init__()
+        self.convert_onnx = False
+        self.pyramid_sizes = None
+        self.P5_1 = nn.Conv2d(C5_size, feature_size, kernel_size=1, stride=1, padding=0)
+        self.P5_upsampled = nn.Upsample(scale_factor=2, mode='nearest')
+        self.P5_2 = nn.Conv2d(feature_size, feature_size, kernel_size=3, stride=1, padding=1)
+        self.P4_1 = nn.Conv2d(C4_size, feature_size, kernel_size=1, stride=1, padding=0)
+        self.P4_2 = nn.Conv2d(feature_size, feature_size, kernel_size=3, stride=1, padding=1)
+        self.P6 = nn.Conv2d(C5_size, feature_size, kernel_size=5, stride=3, padding=1)
+
+
+class RetinaNetTiny(RetinaNet):
+    """retinanet.py:486-669: stem without max-pool, layer1..3 (BasicBlock only), pyramid levels 2..4,
+    anchor sizes 2^(l+2), ratios (1, 1.5, 2).  The reference switches on `self.training` and takes
+    `(img_batch, annotations)` as ONE argument when training (:578-582)."""
+    _plan_class = engine.RetinaPlanTwoLevel
+    _stage_names = ('layer1', 'layer2', 'layer3')
+    _fpn_names = ('P3_1', 'P3_2', 'P2_1', 'P2_2', 'P4')
+    _input_multiple = 16
+
+    def __init__(self, num_classes, block, layers, iou_threshold=0.5, **kwargs):
+        self.inplanes = 64
+        nn.Module.__init__(self)
+        self.convert_onnx = False
+        self.fixed_size = None
+        self.is_training = False
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.iou_threshold = iou_threshold
+        if block != BasicBlock:
+            raise ValueError('Block type %s not understood' % block)          # retinanet.py:510-518
+        fpn_sizes = [self.layer2[layers[1] - 1].conv2.out_channels, self.layer3[layers[2] - 1].conv2.out_channels]
+        self.fpn = PyramidFeaturesTiny(fpn_sizes[0], fpn_sizes[1])
+        self.regressionModel = RegressionModel(256)
+        self.classificationModel = ClassificationModel(256, num_classes=num_classes)
+        my_pyramid_levels = [2, 3, 4]
+        self.anchors = Anchors(pyramid_levels=my_pyramid_levels, sizes=[int(2 ** (x + 2)) for x in my_pyramid_levels],
+                               ratios=[1, 1.5, 2], **kwargs)
+        self.regressBoxes = BBoxTransform()
+        self.clipBoxes = ClipBoxes()
+        self.focalLoss = losses.FocalLoss()
+        self._finish_init()
+
+    def forward(self, inputs, annotations=None, return_head=False, return_loss=None):
+        if return_head or return_loss is not None or annotations is not None:   # (explicit RetinaNet-style call)
+            return RetinaNet.forward(self, inputs, annotations, return_head,
+                                     True if return_loss is None else return_loss)
+        if self.training:                          # retinanet.py:578-582
+            img_batch, annotations = inputs
+            return RetinaNet.forward(self, img_batch, annotations, False, True)
+        return RetinaNet.forward(self, inputs, None, False, False)
+
+
+class RetinaNetP45P6(RetinaNet):
+    """retinanet.py:722-918: full ResNet (BasicBlock only), pyramid levels 4, 5 and P6 = conv5x5 s3 p1
+    over C5 (stride 96), anchor strides (16, 32, 96), sizes (32, 64, 160), ratios (1, 1.5, 2)."""
+    _plan_class = engine.RetinaPlanTwoLevel
+    _stage_names = ('layer1', 'layer2', 'layer3', 'layer4')
+    _fpn_names = ('P5_1', 'P5_2', 'P4_1', 'P4_2', 'P6')
+    _input_multiple = 96                           # ceil(H/96) cells == conv5x5 s3 p1 over H/32 rows
+
+    def __init__(self, num_classes, block, layers, iou_threshold=0.5, pyramid_levels=[4, 5, 6], **kwargs):
+        self.inplanes = 64
+        nn.Module.__init__(self)
+        self.convert_onnx = False
+        self.fixed_size = None
+        self.is_training = False
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.iou_threshold = iou_threshold
+        self.pyramid_levels = pyramid_levels
+        if block != BasicBlock:
+            raise ValueError('Block type %s not understood' % block)          # retinanet.py:746-756
+        # (the reference indexes layer3 with layers[1] and layer4 with layers[2]: retinanet.py:747)
+        fpn_sizes = [self.layer3[layers[1] - 1].conv2.out_channels, self.layer4[layers[2] - 1].conv2.out_channels]
+        self.fpn = PyramidFeaturesP45P6(fpn_sizes[0], fpn_sizes[1])
+        self.regressionModel = RegressionModel(256)
+        self.classificationModel = ClassificationModel(256, num_classes=num_classes)
+        self.anchors = Anchors(pyramid_levels=self.pyramid_levels, strides=[2 ** 4, 2 ** 5, 3 * (2 ** 5)],
+                               sizes=[2 ** 5, 2 ** 6, int(2.5 * (2 ** 6))], ratios=[1, 1.5, 2], **kwargs)
+        self.regressBoxes = BBoxTransform()
+        self.clipBoxes = ClipBoxes()
+        self.focalLoss = losses.FocalLoss()
+        self._finish_init()
+
+
+def retinanet_tiny(num_classes, pretrained=False, **kwargs):
+    _no_fetch(pretrained)                          # (the reference ignores `pretrained` here: retinanet.py:672-679)
+    return RetinaNetTiny(num_classes, BasicBlock, [2, 2, 2], **kwargs)
+
+
+def retinanet_p45p6(num_classes, pretrained=False, **kwargs):
+    _no_fetch(pretrained)
+    return RetinaNetP45P6(num_classes, BasicBlock, [2, 2, 2, 2], **kwargs)
 
 
 def build_retinanet(name, num_classes=80, pretrained=False, **kwargs):

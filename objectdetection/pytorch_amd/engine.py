@@ -93,6 +93,9 @@ class RetinaPlan(object):
         self.num_classes = self.model.classificationModel.num_classes
         self.A_cell = self.model.anchors.num_anchors_per_cell
         self.input_multiple = 32
+        self.stage_names = ('layer1', 'layer2', 'layer3', 'layer4')
+        self.fpn_names = ('P5_1', 'P5_2', 'P4_1', 'P4_2', 'P3_1', 'P3_2', 'P6', 'P7_2')
+        self.has_maxpool = True
 
     # ------------------------------------------------------------------ bookkeeping
     def new(self, shape, dtype=torch.bfloat16, zero=False):
@@ -133,10 +136,11 @@ class RetinaPlan(object):
             if isinstance(mod, torch.nn.Conv2d) and not mod.weight.permute(0, 2, 3, 1).is_contiguous():
                 raise _lib.Mi355Error('conv weights must be KRSC (channels_last) in memory: call '
                                       'model._channels_last_params()')
+        self._add = add
         self.stem = add('conv1', m.conv1, m.bn1)
         self.stem.need_dgrad = False
         self.blocks = []
-        for li, layer in enumerate([m.layer1, m.layer2, m.layer3, m.layer4]):
+        for li, layer in enumerate([getattr(m, n) for n in self.stage_names]):
             for bi, blk in enumerate(layer):
                 pre = 'layer%d.%d' % (li + 1, bi)
                 rec = {'kind': 'bottleneck' if hasattr(blk, 'conv3') else 'basic'}
@@ -150,8 +154,7 @@ class RetinaPlan(object):
                 rec['stage'] = li
                 self.blocks.append(rec)
         f = m.fpn
-        self.fpn = {n: add('fpn.' + n, getattr(f, n)) for n in
-                    ('P5_1', 'P5_2', 'P4_1', 'P4_2', 'P3_1', 'P3_2', 'P6', 'P7_2')}
+        self.fpn = {n: add('fpn.' + n, getattr(f, n)) for n in self.fpn_names}
         self.reg_tower = [add('regressionModel.conv%d' % i, getattr(m.regressionModel, 'conv%d' % i))
                           for i in range(1, 5)]
         self.reg_out = add('regressionModel.output', m.regressionModel.output)
@@ -348,21 +351,33 @@ class RetinaPlan(object):
         assert pt == pl, 'asymmetric-pad dgrad is only needed by the stem, which has no dgrad'
         probs = dgrad_problems(dy, dx.data_ptr(), H, W, spec.Cpad, spec.R, spec.S, spec.stride, pt,
                                addend=addend, mask=mask)
-        self._gather(self.bwd_steps, probs, spec.w_dgr, spec.Cpad, spec.T, flags=1 if mask_first else 0)
+        for i in range(0, len(probs), ops_conv.MAX_PROBLEMS):        # stride 3: 9 output-parity classes
+            self._gather(self.bwd_steps, probs[i:i + ops_conv.MAX_PROBLEMS], spec.w_dgr, spec.Cpad, spec.T,
+                         flags=1 if mask_first else 0)
         return dx
 
     # ------------------------------------------------------------------ forward
     def _build_forward(self):
+        x = self._stem_fwd()
+        feats = self._stages_fwd(x)
+        self._fpn_fwd(feats)                       # -> self.levels
+        self._heads_fwd()
+
+    def _stem_fwd(self):
         B, H, W = self.B, self.H, self.W
         self.img_nhwc = self.new((B, H, W, 8))
         x = self.conv(self.stem, self.img_nhwc, ACT_RELU)
         self.c1 = x
+        if not self.has_maxpool:                   # RetinaNetTiny: retinanet.py:583-586
+            return x
         P, Q = (x.shape[1] - 1) // 2 + 1, (x.shape[2] - 1) // 2 + 1
         self.mp = self.new((B, P, Q, 64))
         self.mp_idx = self.new((B, P, Q, 64), torch.int8)
         self._step(self.fwd_steps, 'mi355_maxpool3x3s2_fwd', ptr(x), ptr(self.mp), ptr(self.mp_idx),
                    c_int(B), c_int(x.shape[1]), c_int(x.shape[2]), c_int(64))
-        x = self.mp
+        return self.mp
+
+    def _stages_fwd(self, x):
         feats = []
         for rec in self.blocks:
             rec['x'] = x
@@ -378,6 +393,10 @@ class RetinaPlan(object):
             x = rec['out']
             if rec['stage_end']:
                 feats.append(x)
+        return feats
+
+    def _fpn_fwd(self, feats):
+        """retinanet.py:48-69."""
         c3, c4, c5 = feats[1], feats[2], feats[3]
         self.c3, self.c4, self.c5 = c3, c4, c5
         f = self.fpn
@@ -393,8 +412,11 @@ class RetinaPlan(object):
                    c_i64(self.p6.numel()))
         self.p7 = self.conv(f['P7_2'], self.p6relu)
         self.levels = [self.p3, self.p4, self.p5, self.p6, self.p7]
+
+    def _heads_fwd(self):
+        B = self.B
         self.cells = [t.shape[1] * t.shape[2] for t in self.levels]
-        self.cell_off = [sum(self.cells[:i]) for i in range(5)]
+        self.cell_off = [sum(self.cells[:i]) for i in range(len(self.levels))]
         self.ncells = sum(self.cells)
         self.A = self.ncells * self.A_cell
         C = self.num_classes
@@ -455,19 +477,29 @@ class RetinaPlan(object):
 
     # ------------------------------------------------------------------ backward
     def _build_backward(self):
-        B, C = self.B, self.num_classes
+        g_feat = self._heads_bwd()
+        g, extra = self._fpn_bwd(g_feat)
+        g = self._stages_bwd(g, extra)
+        self._stem_bwd(g)
+        self._build_param_grads()
+
+    def _heads_bwd(self):
+        B = self.B
         kc = self.cls_out.Kpad                     # 720 (9 anchors x 80 classes), padded to 8
         kr = self.reg_out.Kpad                     # 40 (36 padded)
         self.gcls = self.new((B, self.ncells, kc), zero=True)       # bf16 d/dlogit, cell rows
         self.greg = self.new((B, self.ncells, kr), zero=True)       # bf16, padded pitch
         self.cls_pitch, self.reg_pitch = kc, kr
-        # ---- heads: output convs, then the towers (levels grouped), feature grads accumulated
+        # output convs, then the towers (levels grouped), feature grads accumulated
         g_feat = [self.new(tuple(lv.shape)) for lv in self.levels]
         self._head_bwd(self.reg_out, self.reg_tower, self.reg_t, self.greg, kr, g_feat, first=True)
         self._head_bwd(self.cls_out, self.cls_tower, self.cls_t, self.gcls, kc, g_feat, first=False)
+        return g_feat
+
+    def _fpn_bwd(self, g_feat):
+        """retinanet.py:48-69 reversed -> (gradient of the last stage output, {stage: lateral grad})."""
         g_p3, g_p4, g_p5, g_p6, g_p7 = g_feat
         f = self.fpn
-        # ---- FPN (retinanet.py:48-69 reversed)
         self.conv_bwd(f['P7_2'], self.p6relu, g_p7, dx=g_p6, addend=g_p6, mask=self.p6, mask_first=True)
         g_c5 = self.conv_bwd(f['P6'], self.c5, g_p6)
         g_p5lat = self.conv_bwd(f['P5_2'], self.p5lat, g_p5)
@@ -479,9 +511,10 @@ class RetinaPlan(object):
         g_c4 = self.conv_bwd(f['P4_1'], self.c4, g_p4lat)
         # c5 has no later consumer: finish it here (sum of P6 and P5_1 grads, ReLU of layer4)
         self.conv_bwd(f['P5_1'], self.c5, g_p5lat, dx=g_c5, addend=g_c5, mask=self.c5)
-        # ---- backbone, last block first.  g = gradient w.r.t. the block output's pre-ReLU sum.
-        extra = {2: g_c4, 1: g_c3}                 # raw FPN-lateral grads of the stage outputs
-        g = g_c5
+        return g_c5, {2: g_c4, 1: g_c3}            # raw FPN-lateral grads of the stage outputs
+
+    def _stages_bwd(self, g, extra):
+        """Backbone, last block first.  g = gradient w.r.t. the block output's pre-ReLU sum."""
         for i in range(len(self.blocks) - 1, -1, -1):
             rec = self.blocks[i]
             x = rec['x']
@@ -489,7 +522,8 @@ class RetinaPlan(object):
             x_extra = None
             if i > 0 and self.blocks[i - 1]['stage_end'] and self.blocks[i - 1]['stage'] in extra:
                 x_extra = extra[self.blocks[i - 1]['stage']]
-            mask_x = None if first_block else x    # x = max-pool output for the very first block
+            # x = max-pool output for the very first block (its ReLU mask is applied by the pool backward)
+            mask_x = None if (first_block and self.has_maxpool) else x
             if rec['kind'] == 'bottleneck':
                 g_b = self.conv_bwd(rec['c3'], rec['b'], g, mask=rec['b'])
                 g_a = self.conv_bwd(rec['c2'], rec['a'], g_b, mask=rec['a'])
@@ -503,12 +537,16 @@ class RetinaPlan(object):
                 assert x_extra is None
                 res_g = g
             g = self.conv_bwd(last, x, g_a, addend=res_g, mask=mask_x)
-        # ---- stem: max-pool backward (+ ReLU mask of the stem output), wgrad only
-        g_c1 = self.new(tuple(self.c1.shape))
-        self._step(self.bwd_steps, 'mi355_maxpool3x3s2_bwd', ptr(g), ptr(self.mp_idx), ptr(g_c1),
-                   ptr(self.c1), c_int(B), c_int(self.c1.shape[1]), c_int(self.c1.shape[2]), c_int(64))
-        self.conv_bwd(self.stem, self.img_nhwc, g_c1, dgrad=False)
-        self._build_param_grads()
+        return g
+
+    def _stem_bwd(self, g):
+        """max-pool backward (+ ReLU mask of the stem output), stem wgrad only."""
+        if self.has_maxpool:
+            g_c1 = self.new(tuple(self.c1.shape))
+            self._step(self.bwd_steps, 'mi355_maxpool3x3s2_bwd', ptr(g), ptr(self.mp_idx), ptr(g_c1),
+                       ptr(self.c1), c_int(self.B), c_int(self.c1.shape[1]), c_int(self.c1.shape[2]), c_int(64))
+            g = g_c1
+        self.conv_bwd(self.stem, self.img_nhwc, g, dgrad=False)
 
     def _sumpool(self, src, dst):
         N, H, W, C = src.shape
@@ -666,3 +704,38 @@ class RetinaPlan(object):
         self.bwd_steps_alt = self.bwd_steps
         self.bwd_steps = main_steps
         self._carve_grads(0)
+
+
+class RetinaPlanTwoLevel(RetinaPlan):
+    """RetinaNetTiny (retinanet.py:447-669: no max-pool, layer1..3, FPN over (C2, C3) -> [P2, P3, P4])
+    and RetinaNetP45P6 (retinanet.py:682-918: layer1..4, FPN over (C4, C5) -> [P4, P5, P6 = conv5x5 s3]).
+    Same stem/stage/head launches as RetinaPlan; only the pyramid wiring differs."""
+
+    def _meta(self):
+        RetinaPlan._meta(self)
+        m = self.model
+        self.stage_names = tuple(m._stage_names)
+        self.fpn_names = tuple(m._fpn_names)       # (top_1, top_2, low_1, low_2, extra)
+        self.has_maxpool = hasattr(m, 'maxpool')
+        self.input_multiple = m._input_multiple
+
+    def _fpn_fwd(self, feats):
+        top1, top2, low1, low2, extra = (self.fpn[n] for n in self.fpn_names)
+        self.clow, self.ctop = feats[-2], feats[-1]
+        self.toplat = self.conv(top1, self.ctop)
+        self.ptop = self.conv(top2, self.toplat)
+        self.lowlat = self.conv(low1, self.clow, addend=self.toplat, add_shift=1)
+        self.plow = self.conv(low2, self.lowlat)
+        self.pextra = self.conv(extra, self.ctop)
+        self.levels = [self.plow, self.ptop, self.pextra]
+
+    def _fpn_bwd(self, g_feat):
+        top1, top2, low1, low2, extra = (self.fpn[n] for n in self.fpn_names)
+        g_low, g_top, g_extra = g_feat
+        g_ctop = self.conv_bwd(extra, self.ctop, g_extra)
+        g_toplat = self.conv_bwd(top2, self.toplat, g_top)
+        g_lowlat = self.conv_bwd(low2, self.lowlat, g_low)
+        self._sumpool(g_lowlat, g_toplat)
+        g_clow = self.conv_bwd(low1, self.clow, g_lowlat)
+        self.conv_bwd(top1, self.ctop, g_toplat, dx=g_ctop, addend=g_ctop, mask=self.ctop)
+        return g_ctop, {len(self.stage_names) - 2: g_clow}

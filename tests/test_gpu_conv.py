@@ -96,6 +96,9 @@ def test_conv_fwd_splitk(dev, case, ksplit):
                               out_f32=True, ksplit=ksplit) for _ in range(2)]
     _close(outs[0].permute(0, 3, 1, 2), ref, 2e-3)
     assert torch.equal(outs[0], outs[1])
+    unsplit = ops_conv.conv_fwd(xh, w_fwd, K, R, R, stride, pad, bias=b.to(dev), act=ops_conv.ACT_RELU, addend=rh,
+                                out_f32=True)
+    _close(outs[0], unsplit.cpu(), 2e-6)               # same products, fp32 summation order only
     out16 = ops_conv.conv_fwd(xh, w_fwd, K, R, R, stride, pad, bias=b.to(dev), act=ops_conv.ACT_RELU, addend=rh,
                               ksplit=ksplit)
     _close(out16.permute(0, 3, 1, 2), ref, 1e-2)

@@ -62,6 +62,11 @@ def test_effdet_vs_reference_golden(golden_dir, tag):
             if np.linalg.norm(ref) == 0.0:                 # e.g. box-head BN of a level without positives
                 assert np.abs(got).max() <= 1e-6 * (gn + 1e-30), name
                 continue
+            if np.linalg.norm(ref) < 1e-5 * gn:
+                # near-zero gradient (e.g. bifpn.0.p6_w1: two components of +-1e-5 that cancel, at a global
+                # norm of O(10)): differences of large bf16-rounded sums -> absolute check against the norm
+                assert np.abs(got - ref).max() <= 1e-5 * gn, (name, got, ref)
+                continue
             cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
             ratio = float(np.linalg.norm(got) / (np.linalg.norm(ref) + 1e-30))
             worst = min(worst, cos)

@@ -140,3 +140,51 @@ def test_grad_accumulation_and_arena_reuse(golden_dir, dev):
     (cl + rl).sum().backward()
     for k, p in model.named_parameters():
         assert float((p.grad - g1[k]).abs().max()) <= 2e-2 * float(g1[k].abs().max()) + 1e-12, k
+
+
+@pytest.mark.parametrize('tag', ['tiny_64x96', 'p45p6_192x288'])
+def test_three_level_variants_vs_reference_golden(golden_dir, dev, tag):
+    """RetinaNetTiny (retinanet.py:486-679, `forward((img, annot))` switching on self.training) and
+    RetinaNetP45P6 (retinanet.py:722-922, P6 = conv5x5 stride 3): state_dict keys, anchors, losses,
+    sampled parameter gradients and the decode tail against the reference's outputs."""
+    from objectdetection.pytorch_amd.architectures import retinanet
+    g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
+    kind, (H, W), B, nc = str(g['kind']), g['hw'], int(g['batch']), int(g['num_classes'])
+    model = {'tiny': retinanet.retinanet_tiny, 'p45p6': retinanet.retinanet_p45p6}[kind](nc)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert list(shapes.keys()) == list(g['state_keys'])
+    sd = synth.synth_state_dict(shapes, seed=0, gain=float(g['gain']))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    model.train()
+    model.freeze_bn()
+    img = torch.from_numpy(synth.synth_images(B, int(H), int(W), seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(B, int(H), int(W), 8, 16, nc, seed=2)).to(dev)
+    np.testing.assert_allclose(model.anchors(img).cpu().numpy(), g['anchors'], rtol=1e-6, atol=1e-4)
+    cl, rl = model((img, ann)) if kind == 'tiny' else model(img, ann)
+    np.testing.assert_allclose(cl.item(), g['cls_loss'].item(), rtol=3e-2)
+    np.testing.assert_allclose(rl.item(), g['reg_loss'].item(), rtol=3e-2)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = dict((k, p.grad) for k, p in model.named_parameters())
+    gn = np.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values()))
+    np.testing.assert_allclose(gn, float(g['grad_global_norm']), rtol=5e-2)
+    for key in g.files:
+        if key.startswith('grad/') and key.endswith('/val'):
+            name = key[5:-4]
+            sel = torch.from_numpy(g['grad/%s/idx' % name]).to(dev)
+            got, ref = grads[name].reshape(-1)[sel].cpu().numpy(), g[key]
+            if np.linalg.norm(ref) < 1e-12:
+                assert np.linalg.norm(got) < 1e-6
+                continue
+            cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+            ratio = float(np.linalg.norm(got) / (np.linalg.norm(ref) + 1e-30))
+            assert cos > 0.95 and 0.8 < ratio < 1.25, (name, cos, ratio)
+    model.eval()
+    s, c, b = model(img[:1]) if kind == 'tiny' else model(img[:1], return_loss=False)
+    ref_s = g['det_scores']
+    # bf16 scores move detections across the NMS / 0.05 thresholds: compare the confident head of the list
+    top = min(10, len(ref_s), s.numel())
+    np.testing.assert_allclose(s[:top].cpu().numpy(), ref_s[:top], rtol=0.1, atol=2e-2)
+    assert abs(s.numel() - len(ref_s)) <= max(3, len(ref_s) // 5)
+    assert c.dtype == torch.int64 and b.shape == (s.numel(), 4)

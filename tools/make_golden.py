@@ -287,6 +287,50 @@ def gen_e2e(depth, H, W, B, num_classes, tag, gain):
           'gnorm', d['grad_global_norm'])
 
 
+def gen_e2e_variant(kind, H, W, B, num_classes, tag, gain):
+    """RetinaNetTiny (retinanet.py:486-679) / RetinaNetP45P6 (retinanet.py:722-922): three-level variants."""
+    torch.manual_seed(0)
+    ctor = {'tiny': ref_retinanet.retinanet_tiny, 'p45p6': ref_retinanet.retinanet_p45p6}[kind]
+    model = ctor(num_classes)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=gain)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.train()
+    model.freeze_bn()
+    img = synth.synth_images(B, H, W, seed=1)
+    ann = synth.synth_annotations(B, H, W, num_real=8, pad_to=16, num_classes=num_classes, seed=2)
+    img_t, ann_t = torch.from_numpy(img), torch.from_numpy(ann)
+    if kind == 'tiny':
+        cl, rl = model((img_t, ann_t))                            # retinanet.py:578-582
+    else:
+        cl, rl = model(img_t, ann_t)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters()}
+    d = dict(cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(), kind=np.array(kind), hw=np.array([H, W]),
+             batch=np.array(B), num_classes=np.array(num_classes), gain=np.array(gain))
+    for k in sorted(grads)[::7] + [k for k in grads if k.startswith('fpn.')]:
+        g = grads[k]
+        flat = g.reshape(-1)
+        sel = np.linspace(0, flat.size - 1, min(flat.size, 512)).astype(np.int64)
+        d['grad/' + k + '/idx'] = sel
+        d['grad/' + k + '/val'] = flat[sel]
+    d['grad_global_norm'] = np.array(np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in grads.values())))
+    d['state_keys'] = np.array(list(shapes.keys()))
+    d['state_shapes'] = np.array([','.join(map(str, shapes[k])) for k in shapes])
+    d['anchors'] = model.anchors(img_t).numpy()
+    model.eval()
+    with torch.no_grad():
+        if kind == 'tiny':
+            s, c, b = model(img_t[:1])
+        else:
+            s, c, b = model(img_t[:1], return_loss=False)
+    d['det_scores'], d['det_classes'], d['det_boxes'] = s.numpy(), c.numpy(), b.numpy()
+    np.savez_compressed(os.path.join(OUT, 'e2e_%s.npz' % tag), **d)
+    print('e2e', tag, 'cls', cl.item(), 'reg', rl.item(), 'dets', s.shape, 'gnorm', d['grad_global_norm'],
+          'anchors', d['anchors'].shape)
+
+
 EFF_GRAD_KEYS = ['backbone_net.model._conv_stem.conv.weight', 'backbone_net.model._bn0.weight',
                  'backbone_net.model._blocks.0._depthwise_conv.conv.weight',
                  'backbone_net.model._blocks.0._se_reduce.conv.weight',
@@ -357,13 +401,16 @@ def gen_e2e_effdet(coef, H, W, B, num_classes, tag, gain, head_std):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['anchors', 'loss', 'decode', 'e2e', 'effdet']
+    which = sys.argv[1:] or ['anchors', 'loss', 'decode', 'e2e', 'effdet', 'variants']
     if 'anchors' in which:
         gen_anchors()
     if 'loss' in which:
         gen_loss()
     if 'decode' in which:
         gen_decode()
+    if 'variants' in which:
+        gen_e2e_variant('tiny', 64, 96, 2, 12, 'tiny_64x96', 0.9)
+        gen_e2e_variant('p45p6', 192, 288, 1, 12, 'p45p6_192x288', 0.87)
     if 'e2e' in which:
         gen_e2e(18, 256, 256, 2, 80, 'r18_256', 0.87)     # BASELINE.json configs[0]
         gen_e2e(50, 128, 160, 1, 20, 'r50_128x160', 0.78) # bottleneck path, ragged H != W
