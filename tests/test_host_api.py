@@ -37,6 +37,29 @@ def test_state_dict_matches_reference(golden_dir, tag, depth):
     assert model.layer1[0].conv1.weight.stride(1) == 1
 
 
+@pytest.mark.parametrize('tag,ctor', [('tiny_64x96', 'retinanet_tiny'), ('p45p6_192x288', 'retinanet_p45p6')])
+def test_three_level_variant_state_dict_and_anchor_config(golden_dir, tag, ctor):
+    """retinanet_tiny / retinanet_p45p6 (retinanet.py:672-679, :921-923): state_dict keys + shapes and the
+    anchor configuration (levels, strides, sizes, ratios) of the reference."""
+    from objectdetection.pytorch_amd.architectures import retinanet
+    g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
+    model = getattr(retinanet, ctor)(int(g['num_classes']))
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g['state_keys']]
+    assert [','.join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g['state_shapes']]
+    a = model.anchors
+    if ctor == 'retinanet_tiny':
+        assert [list(map(float, v)) for v in (a.pyramid_levels, a.strides, a.sizes, a.ratios)] == \
+            [[2, 3, 4], [4, 8, 16], [16, 32, 64], [1, 1.5, 2]]
+        assert not hasattr(model, 'maxpool') and not hasattr(model, 'layer4')
+    else:
+        assert [list(map(float, v)) for v in (a.pyramid_levels, a.strides, a.sizes, a.ratios)] == \
+            [[4, 5, 6], [16, 32, 96], [32, 64, 160], [1, 1.5, 2]]
+        assert model.fpn.P6.kernel_size == (5, 5) and model.fpn.P6.stride == (3, 3)
+    with pytest.raises(RuntimeError):
+        getattr(retinanet, ctor)(3, pretrained=True)
+
+
 def test_factories_and_attrs():
     from objectdetection.pytorch_amd.architectures import retinanet, anchors, losses, utils
     m = retinanet.build_retinanet('retinanet-res18', num_classes=3)
