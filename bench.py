@@ -233,7 +233,8 @@ def main():
     else:
         from objectdetection.pytorch_amd.trainer import Trainer
         trainer = Trainer(model, lr=1e-4, weight_decay=5e-4, clip_norm=0.1,   # train.py:259-260, 320
-                          graph=bool(args.graph), max_annots=ann.shape[1])
+                          graph=bool(args.graph), max_annots=ann.shape[1],
+                          overlap=os.environ.get('MI355_DP_OVERLAP', '1') != '0')
 
         def step():
             loss_acc.add_(trainer.step(img, ann))                 # fwd+loss+bwd+allreduce+clip+AdamW
@@ -267,6 +268,7 @@ def main():
                                'and optimizer), batch=%d/GPU, fwd+FocalLoss+bwd+clip+AdamW, frozen BN'
                                % (name, S, S, B),
                    'global_batch': world * B, 'parallelism': 'dp%d' % world,
+                   'dp_exchange': ('per-range all-reduce overlapped with backward' if os.environ.get('MI355_DP_OVERLAP', '1') != '0' else 'one all-reduce after backward') if world > 1 else None,
                    'launch': 'hipGraph replay' if (args.graph and not args.torch_optim) else 'eager',
                    'final_loss': [round(float(v), 5) for v in (loss_acc / (args.warmup + args.steps)).tolist()]},
     }

@@ -314,6 +314,7 @@ class RetinaPlan(object):
                                 granule=int(os.environ.get('MI355_WG_GRANULE', '64')))
         self.keep.append(L)
         spec._wgrad_launch = L
+        spec._wgrad_end = len(self.bwd_steps) + 1          # launches of the backward list needed for this dW
         if not self.deterministic:
             self._step(self.bwd_steps, 'mi355_conv_wgrad_colsum', ctypes.byref(L), ptr(spec.G),
                        ptr(spec.colsum if colsum else None), c_int(split))
@@ -606,26 +607,66 @@ class RetinaPlan(object):
         self.pgrad_specs = [s for s in self.specs if not s.direct]
         self.pgrad_tables = {}
 
-    def _run_param_grads(self, arena, stream):
+    def _run_param_grads(self, arena, stream, segment=None):
+        """`segment` = (lo, hi) arena range: only the layers whose weights live there (overlapped DP
+        exchange); None = every layer."""
         if not self.pgrad_specs:
             return
-        tab = self.pgrad_tables.get(arena)
+        key = (arena, segment)
+        tab = self.pgrad_tables.get(key)
         if tab is None:
             self._carve_grads(arena)
             seen, descs, nb = {}, [], 0
             for s in self.pgrad_specs:
                 seen[id(s.conv)] = seen.get(id(s.conv), 0) + 1
             for s in self.pgrad_specs:
+                if segment is not None and not (segment[0] <= self.grad_offsets[id(s.conv.weight)] < segment[1]):
+                    continue
                 d = self._layer_desc(s, arena)
                 d.atomic = 1 if seen[id(s.conv)] > 1 else 0
                 d.block_begin = nb
                 nb += s.K
                 descs.append(d)
-            tab = (ops_conv.upload_table(descs, self.dev), len(descs), nb)
-            self.pgrad_tables[arena] = tab
+            tab = (ops_conv.upload_table(descs, self.dev), len(descs), nb) if descs else None
+            self.pgrad_tables[key] = tab or ()
+        if not tab:
+            return
         rc = self.lib.mi355_param_grads_table(ptr(tab[0]), c_int(tab[1]), c_int(tab[2]), c_vp(stream))
         if rc:
             raise _lib.Mi355Error('param_grads_table: %s' % self.lib.mi355_last_error().decode())
+
+    def backward_segments(self, min_bytes=16 << 20):
+        """Cut the backward pass for an overlapped data-parallel exchange: [(n_steps, lo, hi)] in execution
+        order, meaning "after the first n_steps backward launches (+ the parameter-gradient table of
+        arena range [lo, hi)) the gradients in [lo, hi) are final".  Ranges are cut at top-level module
+        boundaries (parameters() order is stem, stages, pyramid, heads; backward runs the other way), each
+        at least `min_bytes` so that a collective stays xGMI-efficient."""
+        if getattr(self, '_segments', None) is not None:
+            return self._segments
+        ready = {}
+        for s in self.specs:
+            end = getattr(s, '_wgrad_end', len(self.bwd_steps))
+            for p in (s.conv.weight, s.conv.bias, getattr(s.bn, 'weight', None), getattr(s.bn, 'bias', None)):
+                if p is not None:
+                    ready[id(p)] = max(ready.get(id(p), 0), end)
+        bounds = []                                   # (offset, ready step) per top-level child, in order
+        for _, child in self.model.named_children():
+            ps = list(child.parameters())
+            if ps:
+                bounds.append((self.grad_offsets[id(ps[0])],
+                               max(ready.get(id(p), len(self.bwd_steps)) for p in ps)))
+        segs, hi, rdy = [], self.grad_numel_padded, 0
+        for off, r in reversed(bounds):
+            rdy = max(rdy, r)
+            if (hi - off) * 4 >= min_bytes or off == bounds[0][0]:
+                lo = 0 if off == bounds[0][0] else off
+                segs.append([rdy, lo, hi])
+                hi, rdy = lo, 0
+        for i in range(1, len(segs)):                 # execution order must be monotone
+            segs[i][0] = max(segs[i][0], segs[i - 1][0])
+        segs[-1][0] = len(self.bwd_steps)
+        self._segments = [tuple(x) for x in segs]
+        return self._segments
 
     # ------------------------------------------------------------------ execution
     def _stream(self):
@@ -657,7 +698,8 @@ class RetinaPlan(object):
                   ptr(self.loss_ws), c_i64(self.loss_ws_bytes), c_vp(self._stream()))
         return self.losses
 
-    def run_backward(self, g_cls, g_reg):
+    def begin_backward(self, g_cls, g_reg):
+        """Zero the gradient arena, loss backward (d loss / d head outputs).  Returns the arena index."""
         st = self._stream()
         arena = self._arena_for_backward()
         self.last_arena = arena
@@ -672,6 +714,21 @@ class RetinaPlan(object):
                   c_int(self.B), c_int(self.A), c_int(self.num_classes), c_int(annot.shape[1]),
                   c_f32(ops_detect.ALPHA), c_int(1), ptr(self.gcls), ptr(self.greg),
                   c_int(self.A_cell), c_int(self.cls_pitch), c_int(self.reg_pitch), c_vp(st))
+        self._bwd_pos = 0
+        return arena
+
+    def run_backward_segment(self, seg):
+        """Backward launches up to seg[0], then the parameter gradients of arena range [seg[1], seg[2])."""
+        st = self._stream()
+        arena = self.last_arena
+        steps = self.bwd_steps if arena == 0 else self.bwd_steps_alt
+        self._run(steps[self._bwd_pos:seg[0]], st)
+        self._bwd_pos = seg[0]
+        self._run_param_grads(arena, st, (seg[1], seg[2]))
+
+    def run_backward(self, g_cls, g_reg):
+        arena = self.begin_backward(g_cls, g_reg)
+        st = self._stream()
         self._run(self.bwd_steps if arena == 0 else self.bwd_steps_alt, st)
         self._run_param_grads(arena, st)
         self._extra_param_grads(arena, st)

@@ -16,13 +16,15 @@ from ._lib import c_f32, c_i64, c_int, c_vp, ptr
 
 class Trainer(object):
     def __init__(self, model, lr=1e-4, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8,
-                 clip_norm=0.1, group=None, bucket_bytes=0, graph=False, max_annots=128):
+                 clip_norm=0.1, group=None, bucket_bytes=0, graph=False, max_annots=128, overlap=True,
+                 segment_bytes=16 << 20):
         """graph=True replays the step from two captured hipGraphs (forward+loss+backward | clip+AdamW;
         the RCCL all-reduce stays between them on the stream): ~400-2000 launches cost one graph
         launch each.  Inputs are copied into static buffers; annotations are padded with -1 rows
         to `max_annots` (pad rows are ignored exactly, losses.py:50)."""
         self.model, self.group, self.bucket_bytes = model, group, bucket_bytes
         self.use_graph, self.max_annots = graph, max_annots
+        self.overlap, self.segment_bytes = overlap, segment_bytes
         self._graphs = None
         self.lr, self.wd, self.betas, self.eps, self.clip_norm = lr, weight_decay, betas, eps, clip_norm
         self.lib = _lib.lib()
@@ -58,9 +60,56 @@ class Trainer(object):
     def step(self, img, annot):
         if self.use_graph:
             return self._step_graph(img, annot)
+        if self._overlap():
+            plan, losses = self._fwd_bwd_overlapped(img, annot)
+            self._update(plan, dp.reduce_losses_(losses.clone(), self.group))
+            return losses
         plan, losses = self._fwd_bwd(img, annot)
         self._exchange_and_update(plan, losses)
         return losses
+
+    # ------------------------------------------------------------------ overlapped DP exchange
+    def _overlap(self):
+        """world > 1: the gradient arena is exchanged in a few large tail ranges, each all-reduced on the
+        RCCL stream as soon as the backward pass has finished it (heads, pyramid, layer4, ... in that
+        order), while the remaining backward launches keep the compute stream busy."""
+        from . import engine
+        pc = getattr(type(self.model), '_plan_class', None)      # (EfficientDet's tape-built backward: one exchange)
+        return (dp.world(self.group)[1] > 1 and self.overlap and pc is not None and
+                pc._build_backward is engine.RetinaPlan._build_backward)
+
+    def _allreduce_async(self, t):
+        import torch.distributed as dist
+        size = dp.world(self.group)[1]
+        if dist.get_backend(self.group) == 'nccl':                       # RCCL: average inside the collective
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), 1.0 / size
+
+    def _begin(self, img, annot):
+        model = self.model
+        plan = model._plan(img)
+        anchors = model.anchors(img)
+        plan.run_heads(img)
+        losses = plan.run_loss(anchors, annot)
+        plan.begin_backward(self.ones[0:1], self.ones[1:2])
+        return plan, losses
+
+    def _finish_exchange(self, plan, works):
+        grad = plan.grad_arenas[plan.last_arena]
+        for (w, scale), seg in works:
+            w.wait()
+            if scale is not None:
+                grad[seg[1]:seg[2]].mul_(scale)
+
+    def _fwd_bwd_overlapped(self, img, annot):
+        plan, losses = self._begin(img, annot)
+        grad = plan.grad_arenas[plan.last_arena]
+        works = []
+        for seg in plan.backward_segments(self.segment_bytes):
+            plan.run_backward_segment(seg)
+            works.append((self._allreduce_async(grad[seg[1]:seg[2]]), seg))
+        self._finish_exchange(plan, works)
+        return plan, losses
 
     def _fwd_bwd(self, img, annot):
         model = self.model
@@ -101,14 +150,30 @@ class Trainer(object):
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                plan, losses = self._fwd_bwd(self._s_img, self._s_ann)
-                self._update(plan, self._exchange(plan, losses))
+                if self._overlap():
+                    plan, losses = self._fwd_bwd_overlapped(self._s_img, self._s_ann)
+                    self._update(plan, dp.reduce_losses_(losses.clone(), self.group))
+                else:
+                    plan, losses = self._fwd_bwd(self._s_img, self._s_ann)
+                    self._update(plan, self._exchange(plan, losses))
                 first = losses.clone()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                plan, losses = self._fwd_bwd(self._s_img, self._s_ann)
+            self._g_segs = []
+            if self._overlap():
+                # one graph per backward piece; the all-reduce of a finished arena range is issued between
+                # two replays and runs on the RCCL stream under the next piece
+                with torch.cuda.graph(g1):
+                    plan, losses = self._begin(self._s_img, self._s_ann)
+                for seg in plan.backward_segments(self.segment_bytes):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=g1.pool()):
+                        plan.run_backward_segment(seg)
+                    self._g_segs.append((g, seg))
+            else:
+                with torch.cuda.graph(g1):
+                    plan, losses = self._fwd_bwd(self._s_img, self._s_ann)
             self._g_plan, self._g_losses = plan, losses
             with torch.cuda.graph(g2, pool=g1.pool()):
                 self._update(plan, self._s_flag)
@@ -116,7 +181,17 @@ class Trainer(object):
             return first                           # this step already ran eagerly (the warm-up)
         g1, g2 = self._graphs
         g1.replay()
-        self._s_flag.copy_(self._exchange(self._g_plan, self._g_losses))
+        if self._g_segs:
+            plan = self._g_plan
+            grad = plan.grad_arenas[plan.last_arena]
+            works = []
+            for g, seg in self._g_segs:
+                g.replay()
+                works.append((self._allreduce_async(grad[seg[1]:seg[2]]), seg))
+            self._finish_exchange(plan, works)
+            self._s_flag.copy_(dp.reduce_losses_(self._g_losses.clone(), self.group))
+        else:
+            self._s_flag.copy_(self._exchange(self._g_plan, self._g_losses))
         g2.replay()
         return self._g_losses
 

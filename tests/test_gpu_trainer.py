@@ -164,3 +164,49 @@ def test_deterministic_split_k_mode(monkeypatch):
         assert torch.equal(a[k], b[k]), k                    # bit-reproducible
         ref = base[k]
         assert float((a[k] - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-9, k
+
+
+def _dp_worker(rank, world, port, out):
+    """Two ranks (gloo; both on the one GPU of the test box) x {one exchange after backward, overlapped
+    per-range exchange} x {eager, hipGraph}: same batches -> same parameters."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from objectdetection.pytorch_amd.trainer import Trainer
+        dev = torch.device('cuda', 0)
+        img = torch.from_numpy(synth.synth_images(2, 128, 128, seed=10 + rank)).to(dev)
+        ann = torch.from_numpy(synth.synth_annotations(2, 128, 128, 6, 8, 8, seed=20 + rank)).to(dev)
+        res = {}
+        for name, overlap, graph in (('single', False, False), ('overlap', True, False), ('overlap_graph', True, True)):
+            model = _model(dev)
+            tr = Trainer(model, lr=1e-3, clip_norm=0.1, overlap=overlap, graph=graph, max_annots=8,
+                         segment_bytes=4 << 20)
+            losses = [tr.step(img, ann).clone() for _ in range(3)]
+            plan = model._plans[next(iter(model._plans))]
+            res[name] = dict(flat=tr.flat.cpu().numpy(), loss=torch.stack(losses).cpu().numpy(),
+                             nseg=len(plan.backward_segments(4 << 20)), steps=tr.step_count)
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_dp_exchange_two_ranks():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0['overlap']['nseg'] >= 3 and r0['single']['steps'] == 3
+    for name in ('single', 'overlap', 'overlap_graph'):
+        assert np.array_equal(r0[name]['flat'], r1[name]['flat']), name       # replicas stay identical
+    # the ranges partition the arena and a two-rank sum is order independent: bit-identical parameters
+    assert np.array_equal(r0['single']['flat'], r0['overlap']['flat'])
+    assert np.array_equal(r0['single']['flat'], r0['overlap_graph']['flat'])
+    assert not np.array_equal(r0['single']['loss'], r1['single']['loss'])    # different shards
