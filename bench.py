@@ -269,7 +269,7 @@ def main():
                                % (name, S, S, B),
                    'global_batch': world * B, 'parallelism': 'dp%d' % world,
                    'dp_exchange': ('per-range all-reduce overlapped with backward' if os.environ.get('MI355_DP_OVERLAP', '1') != '0' else 'one all-reduce after backward') if world > 1 else None,
-                   'launch': 'hipGraph replay' if (args.graph and not args.torch_optim) else 'eager',
+                   'launch': 'hipGraph replay' if (args.graph and not args.torch_optim and not (world > 1 and os.environ.get('MI355_DP_OVERLAP', '1') != '0')) else 'eager',
                    'final_loss': [round(float(v), 5) for v in (loss_acc / (args.warmup + args.steps)).tolist()]},
     }
     plan = model._plans[next(iter(model._plans))]

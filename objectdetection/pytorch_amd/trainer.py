@@ -58,9 +58,11 @@ class Trainer(object):
         return int(self.state[0].item())
 
     def step(self, img, annot):
-        if self.use_graph:
+        if self.use_graph and not self._overlap():
             return self._step_graph(img, annot)
         if self._overlap():
+            # (launched eagerly: the step is GPU-bound, ~260 launches cost ~2 ms of host time per ~14 ms
+            # step, and collectives issued between hipGraph replays serialised badly in rehearsal)
             plan, losses = self._fwd_bwd_overlapped(img, annot)
             self._update(plan, dp.reduce_losses_(losses.clone(), self.group))
             return losses
@@ -150,30 +152,14 @@ class Trainer(object):
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                if self._overlap():
-                    plan, losses = self._fwd_bwd_overlapped(self._s_img, self._s_ann)
-                    self._update(plan, dp.reduce_losses_(losses.clone(), self.group))
-                else:
-                    plan, losses = self._fwd_bwd(self._s_img, self._s_ann)
-                    self._update(plan, self._exchange(plan, losses))
+                plan, losses = self._fwd_bwd(self._s_img, self._s_ann)
+                self._update(plan, self._exchange(plan, losses))
                 first = losses.clone()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            self._g_segs = []
-            if self._overlap():
-                # one graph per backward piece; the all-reduce of a finished arena range is issued between
-                # two replays and runs on the RCCL stream under the next piece
-                with torch.cuda.graph(g1):
-                    plan, losses = self._begin(self._s_img, self._s_ann)
-                for seg in plan.backward_segments(self.segment_bytes):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=g1.pool()):
-                        plan.run_backward_segment(seg)
-                    self._g_segs.append((g, seg))
-            else:
-                with torch.cuda.graph(g1):
-                    plan, losses = self._fwd_bwd(self._s_img, self._s_ann)
+            with torch.cuda.graph(g1):
+                plan, losses = self._fwd_bwd(self._s_img, self._s_ann)
             self._g_plan, self._g_losses = plan, losses
             with torch.cuda.graph(g2, pool=g1.pool()):
                 self._update(plan, self._s_flag)
@@ -181,17 +167,7 @@ class Trainer(object):
             return first                           # this step already ran eagerly (the warm-up)
         g1, g2 = self._graphs
         g1.replay()
-        if self._g_segs:
-            plan = self._g_plan
-            grad = plan.grad_arenas[plan.last_arena]
-            works = []
-            for g, seg in self._g_segs:
-                g.replay()
-                works.append((self._allreduce_async(grad[seg[1]:seg[2]]), seg))
-            self._finish_exchange(plan, works)
-            self._s_flag.copy_(dp.reduce_losses_(self._g_losses.clone(), self.group))
-        else:
-            self._s_flag.copy_(self._exchange(self._g_plan, self._g_losses))
+        self._s_flag.copy_(self._exchange(self._g_plan, self._g_losses))
         g2.replay()
         return self._g_losses
 
