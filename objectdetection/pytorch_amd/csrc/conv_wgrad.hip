@@ -53,6 +53,7 @@ struct WLaunch {
     int nprob, K, T, k_tiles, c_tiles, ntaps, split_rows, dbg;
     // grouped launches: chunks sorted by length (longest first), so that the short chunks of the small
     // pyramid levels fill the tail of the launch instead of opening a second round of full-length blocks
+    int ub;                                     // XCD-local unit size in logical blocks (1: none)
     int nsorted;                                // 0: chunk -> problem by chunk_begin (single problem)
     unsigned char ch_prob[MAX_SORTED];
     int ch_mbegin[MAX_SORTED];
@@ -83,9 +84,15 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
     __shared__ float s_cs[TK];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    // block -> (chunk, tap, k_tile, c_tile); tiles of one chunk are adjacent so that the
-    // activation rows they share stay in L2.
+    // block -> (chunk, tap, k_tile, c_tile).  Consecutive blockIdx round-robin over the 8 XCDs (one L2
+    // each).  When the launch divides into a multiple of 8 equal units of `ub` consecutive logical
+    // blocks that read the same rows (a whole pixel chunk, or its per-tap tile group), unit u runs on
+    // XCD u % 8, so that its rows are fetched into ONE L2 instead of all eight (ub == 1: plain order).
     int b = blockIdx.x;
+    if (L.ub > 1) {
+        const int idx = blockIdx.x >> 3;
+        b = ((blockIdx.x & 7) + 8 * (idx / L.ub)) * L.ub + idx % L.ub;
+    }
     const int c_tile = b % L.c_tiles;  b /= L.c_tiles;
     const int k_tile = b % L.k_tiles;  b /= L.k_tiles;
     const int tap = b % L.ntaps;       b /= L.ntaps;
@@ -462,6 +469,17 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
     if (flat) L.ntaps = 1;
     const long long grid = (long long)chunks * L.ntaps * L.k_tiles * L.c_tiles;
     MI355_REQUIRE(grid > 0 && grid < 0x7fffffffLL, "conv_wgrad: grid");
+    static const int unit_mode = [] {
+        const char* e = getenv("MI355_WG_UNITS");
+        return e ? atoi(e) : 1;
+    }();
+    L.ub = 1;
+    if (unit_mode && in.nprob == 1) {                  // equal chunks (but the last): balanced iff #units % 8 == 0
+        const int tpc = L.ntaps * L.k_tiles * L.c_tiles;
+        const int cand[2] = {tpc, L.k_tiles * L.c_tiles};      // whole chunk, or one tap's tiles of a chunk
+        for (int i = 0; i < 2; ++i)
+            if (cand[i] > 1 && grid % cand[i] == 0 && (grid / cand[i]) % 8 == 0) { L.ub = cand[i]; break; }
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
