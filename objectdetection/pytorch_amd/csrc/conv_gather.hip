@@ -390,17 +390,23 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
     if (ksteps > 0) issue(0, 0);
     // (bias loads are issued behind the first stage's DMA so that both latencies overlap)
     init_acc(acc, L, n0, wn, fq);
-    if (STAGES == 3) {
-        // three-stage ring: stage ks is read while ks+1 and ks+2 are in flight.  Per thread a stage is
-        // 4 + NB DMA instructions; `vmcnt(4 + NB)` therefore retires stage ks and leaves ks+1 flying.
-        if (ksteps > 1) issue(1, 1);
+    if (STAGES >= 3) {
+        // ring of STAGES buffers: stage ks is read while the next STAGES - 2 are in flight.  Per thread a
+        // stage is 4 + NB DMA instructions, so `vmcnt(r * (4 + NB))` retires stage ks and leaves the r
+        // younger stages flying (a raw s_barrier: __syncthreads would drain vmcnt to 0).
+        constexpr int D = STAGES - 1, G = 4 + NB;
+#pragma unroll
+        for (int i = 1; i < D; ++i)
+            if (i < ksteps) issue(i, i);
         for (int ks = 0; ks < ksteps; ++ks) {
             // (lgkmcnt(0): this wave's ds_reads of the buffer refilled below have landed)
-            if (ks + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + NB) : "memory");
+            const int r = min(D - 1, ksteps - 1 - ks);
+            if (r >= 2 && D > 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * G) : "memory");
+            else if (r == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();              // raw: no vmcnt(0) drain (unlike __syncthreads)
-            if (ks + 2 < ksteps) issue(ks + 2, (ks + 2) % 3);
-            compute(ks % 3);
+            __builtin_amdgcn_s_barrier();
+            if (ks + D < ksteps) issue(ks + D, (ks + D) % STAGES);
+            compute(ks % STAGES);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -621,6 +627,41 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     const long long ao = n * P.add_sN + (long long)(p >> P.add_shift) * P.add_sH + (long long)(q >> P.add_shift) * P.add_sW;
     const float* w = ws + (long long)m * K + k0;
     const int nv = min(8, K - k0);
+    if ((K & 7) == 0) {                                // 16-B path (every split-K launch of the plans)
+        float x[8];
+        {
+            const float4 a = *reinterpret_cast<const float4*>(w), b = *reinterpret_cast<const float4*>(w + 4);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        }
+        for (int sp = 1; sp < ksplit; ++sp) {
+            const float4 a = *reinterpret_cast<const float4*>(w + sp * split_stride);
+            const float4 b = *reinterpret_cast<const float4*>(w + sp * split_stride + 4);
+            x[0] += a.x; x[1] += a.y; x[2] += a.z; x[3] += a.w; x[4] += b.x; x[5] += b.y; x[6] += b.z; x[7] += b.w;
+        }
+        s8v mk = (s8v){0, 0, 0, 0, 0, 0, 0, 0}, ad = mk;
+        if (P.mask) mk = *reinterpret_cast<const s8v*>(P.mask + oo + k0);
+        if (P.addend) ad = *reinterpret_cast<const s8v*>(P.addend + ao + k0);
+        s8v o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = x[e] + (bias ? bias[k0 + e] : 0.0f);
+            const bool on = bf16_to_f32((unsigned short)mk[e]) > 0.0f;
+            if (P.mask && mask_first) v = on ? v : 0.0f;
+            if (P.addend) v += bf16_to_f32((unsigned short)ad[e]);
+            v = activate(v, act);
+            if (P.mask && !mask_first) v = on ? v : 0.0f;
+            x[e] = v;
+            o[e] = (short)f32_to_bf16_rn(v);
+        }
+        if (out_f32) {
+            float* op = reinterpret_cast<float*>(P.out) + oo + k0;
+            *reinterpret_cast<float4*>(op) = make_float4(x[0], x[1], x[2], x[3]);
+            *reinterpret_cast<float4*>(op + 4) = make_float4(x[4], x[5], x[6], x[7]);
+        } else {
+            *reinterpret_cast<s8v*>(reinterpret_cast<unsigned short*>(P.out) + oo + k0) = o;
+        }
+        return;
+    }
     for (int e = 0; e < nv; ++e) {
         float x = w[e];
         for (int sp = 1; sp < ksplit; ++sp) x += w[sp * split_stride + e];
@@ -661,12 +702,13 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     // k-steps of the longest problem decide the pipeline depth; the 256-row / 3-stage variant runs one
     // block per CU, so it needs a long reduction and enough tiles to cover the chip.
     int max_ksteps = 0;
-    long long big_tiles = 0;
+    long long big_tiles = 0, grid128 = 0;
     for (int i = 0; i < in.nprob; ++i) {
         const int taps = in.prob[i].TR * in.prob[i].TS;
         const int ks = flat ? (taps * (C / 8) + 7) / 8 : taps * (C / BK);
         if (ks > max_ksteps) max_ksteps = ks;
         big_tiles += cdiv((long long)in.prob[i].N * in.prob[i].P * in.prob[i].Q, 256);
+        grid128 += cdiv((long long)in.prob[i].N * in.prob[i].P * in.prob[i].Q, 128) * cdiv(in.K, BN);
     }
     const bool single = max_ksteps <= 2 && ksplit <= 1;
     static const int big_min_grid = [] {
@@ -685,6 +727,11 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         row3 = s.TR == 3 && s.TS == 3 && s.sh == 1 && s.sw == 1 && (s.dhs == 1 || s.dhs == -1) &&
                ((s.dws == 1 && s.dw0 == -1) || (s.dws == -1 && s.dw0 == 1)) && s.Q == s.W;
     }
+    static const int deep_over_row3 = [] {
+        const char* e = getenv("MI355_DEEP_OVER_ROW3");
+        return e ? atoi(e) : 288;
+    }();
+    if (deep_over_row3 && grid128 <= deep_over_row3) row3 = false;
     const bool row3_big = row3 && row3_mode == 4;
     const bool big = !row3 && !splitk && !flat && max_ksteps >= 6 && big_min_grid > 0 &&
                      big_tiles * cdiv(in.K, BN) >= big_min_grid;
@@ -762,10 +809,18 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);
         (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);
         (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
+        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
         (void)hipFuncSetAttribute((const void*)conv_gather_row3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ROW3_LDS2);
         (void)hipFuncSetAttribute((const void*)conv_gather_row3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ROW3_LDS4);
         attr_set = true;
     }
+    // at most one 128x128 block per CU anyway: a 4-stage ring (128 KiB) hides the DMA latency that the
+    // two-stage loop exposes when no second block shares the CU
+    static const int deep_max_grid = [] {
+        const char* e = getenv("MI355_GATHER_DEEP");
+        return e ? atoi(e) : 288;
+    }();
+    const bool deep = !flat && !big && !row3 && max_ksteps >= 6 && grid <= deep_max_grid;
     const dim3 g((unsigned)grid);
     hipStream_t st = (hipStream_t)stream;
     if (row3) {
@@ -773,6 +828,8 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         else          hipLaunchKernelGGL((conv_gather_row3_kernel<2>), g, dim3(256), ROW3_LDS2, st, L);
     } else if (big) {
         hipLaunchKernelGGL((conv_gather_kernel<false, 3, 4>), g, dim3(512), 3 * STAGE3, st, L);
+    } else if (deep) {
+        hipLaunchKernelGGL((conv_gather_kernel<false, 4, 2>), g, dim3(256), 4 * STAGE2, st, L);
     } else if (single) {
         if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
         else      hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
