@@ -48,8 +48,9 @@ def parse():
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--graph', type=int, default=int(os.environ.get('MI355_GRAPH', '1')),
-                    help='replay the step from captured hipGraphs (default on)')
+    ap.add_argument('--graph', type=int, default=int(os.environ.get('MI355_GRAPH', '0')),
+                    help='replay the step from captured hipGraphs (default off: the step is GPU-bound and the '
+                         'two-stream schedule runs faster launched eagerly than as a branched graph)')
     ap.add_argument('--torch-optim', action='store_true',
                     help='autograd + torch clip/AdamW instead of the flat HIP optimizer')
     return ap.parse_args()
@@ -149,11 +150,13 @@ def time_conv_kernels(plan, iters):
     st = torch.cuda.current_stream()
     plan.grad_arenas[0].zero_()
     plan._run(steps, st.cuda_stream)
+    plan.join_side()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
     for _ in range(iters):
         plan._run(steps, st.cuda_stream)
+        plan.join_side()          # wgrad launches run on the plan's side stream: fence them into the timing
     e1.record(st)
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters, len(steps)

@@ -76,6 +76,9 @@ class RetinaPlan(object):
             self.wgrad_mode = 'slabs'
         assert self.wgrad_mode in ('slabs', 'atomic')
         self.deterministic = self.wgrad_mode == 'slabs'
+        self.use_side = os.environ.get('MI355_SIDE_STREAM', '1') == '1'
+        self._side, self._side_dirty = None, False
+        self._side_ids, self._mark_side = set(), False
         self.last_arena = 0
         self._meta()
         if H % self.input_multiple or W % self.input_multiple:
@@ -114,13 +117,40 @@ class RetinaPlan(object):
     def _step(self, lst, name, *args):
         self.keep.append(args)
         lst.append((getattr(self.lib, name), args, name))
+        if getattr(self, '_mark_side', False):
+            self._side_ids.add(id(args))
+
+    SIDE_STEPS = ('mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum')
 
     def _run(self, steps, stream):
+        """Launch `steps` on `stream`.  With the side stream enabled (MI355_SIDE_STREAM=1) the weight-gradient
+        launches go to a second HIP stream, forked behind everything issued so far: a wgrad and the data
+        gradient of the same layer only share inputs, so they run concurrently and fill each other's
+        ramp-up / tail; `join_side()` is the fence in front of the consumers of dW."""
         s = c_vp(stream)
+        side = self._side_stream() if self.use_side else None
         for fn, args, name in steps:
-            rc = fn(*args, s)
+            if side is not None and (name in self.SIDE_STEPS or id(args) in self._side_ids):
+                main = torch.cuda.current_stream(self.dev)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                rc = fn(*args, c_vp(side.cuda_stream))
+                self._side_dirty = True
+            else:
+                rc = fn(*args, s)
             if rc:
                 raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, self.lib.mi355_last_error().decode()))
+
+    def _side_stream(self):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
+
+    def join_side(self):
+        if getattr(self, '_side_dirty', False):
+            torch.cuda.current_stream(self.dev).wait_stream(self._side)
+            self._side_dirty = False
 
     # ------------------------------------------------------------------ layers / parameters
     def _collect_layers(self):
@@ -421,11 +451,15 @@ class RetinaPlan(object):
         self.ncells = sum(self.cells)
         self.A = self.ncells * self.A_cell
         C = self.num_classes
-        self.reg_t = self._tower_fwd(self.reg_tower)
-        self.cls_t = self._tower_fwd(self.cls_tower)
         self.reg = self.new((B, self.A, 4), torch.float32)
         self.cls = self.new((B, self.A, C), torch.float32)
+        # the box head only shares the pyramid with the class head: its launches go to the side stream
+        # (when enabled) and run beside the class tower; run_heads joins before the loss
+        self._mark_side = True
+        self.reg_t = self._tower_fwd(self.reg_tower)
         self._head_out_fwd(self.reg_out, self.reg_t[-1], self.reg, 4 * self.A_cell, ACT_NONE)
+        self._mark_side = False
+        self.cls_t = self._tower_fwd(self.cls_tower)
         self._head_out_fwd(self.cls_out, self.cls_t[-1], self.cls, C * self.A_cell, ACT_SIGMOID)
         # loss state
         self.losses = self.new((2,), torch.float32)
@@ -685,6 +719,7 @@ class RetinaPlan(object):
             raise _lib.Mi355Error('nchw_to_nhwc: %s' % self.lib.mi355_last_error().decode())
         self._run(self.prep_steps, st)
         self._run(self.fwd_steps, st)
+        self.join_side()
 
     def run_loss(self, anchors, annot):
         annot = annot.contiguous().float()
@@ -724,12 +759,14 @@ class RetinaPlan(object):
         steps = self.bwd_steps if arena == 0 else self.bwd_steps_alt
         self._run(steps[self._bwd_pos:seg[0]], st)
         self._bwd_pos = seg[0]
+        self.join_side()
         self._run_param_grads(arena, st, (seg[1], seg[2]))
 
     def run_backward(self, g_cls, g_reg):
         arena = self.begin_backward(g_cls, g_reg)
         st = self._stream()
         self._run(self.bwd_steps if arena == 0 else self.bwd_steps_alt, st)
+        self.join_side()
         self._run_param_grads(arena, st)
         self._extra_param_grads(arena, st)
         return [self.grad_view(p, arena) if p.requires_grad else None for p in self.params]
