@@ -128,7 +128,9 @@ class RetinaPlan(object):
         gradient of the same layer only share inputs, so they run concurrently and fill each other's
         ramp-up / tail; `join_side()` is the fence in front of the consumers of dW."""
         s = c_vp(stream)
-        side = self._side_stream() if self.use_side else None
+        # (not while a hipGraph is being captured: a branched graph replayed slower than the single-stream one
+        # and one replay disagreed with the eager schedule; graphs keep the single-stream order)
+        side = self._side_stream() if (self.use_side and not torch.cuda.is_current_stream_capturing()) else None
         for fn, args, name in steps:
             if side is not None and (name in self.SIDE_STEPS or id(args) in self._side_ids):
                 main = torch.cuda.current_stream(self.dev)
