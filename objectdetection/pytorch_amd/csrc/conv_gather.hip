@@ -414,8 +414,8 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
         __syncthreads();
         for (int ks = 0; ks < ksteps; ++ks) {
             const int buf = ks & 1;
-            if (ks + 1 < ksteps && !(L.flags & 256)) issue(ks + 1, buf ^ 1);
-            if (!(L.flags & 512)) compute(buf);
+            if (ks + 1 < ksteps) issue(ks + 1, buf ^ 1);
+            compute(buf);
             __syncthreads();
         }
     } else {
@@ -774,7 +774,6 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     L.w = (const unsigned short*)in.weight;
     L.bias = in.bias;
     L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.act = in.act; L.out_f32 = in.out_f32; L.flags = in.flags;
-    { const char* e = getenv("MI355_DBG"); if (e) L.flags |= atoi(e); }
     L.n_tiles = (int)cdiv(in.K, BN);
     L.w_bytes = (int)w_bytes;
     long long grid = (long long)tiles * L.n_tiles;

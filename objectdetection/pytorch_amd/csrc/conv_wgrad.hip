@@ -50,7 +50,7 @@ struct WLaunch {
     float* dw;
     float* colsum;
     long long slab_stride;      // > 0: plain stores into slab `chunk` (dw + chunk*slab_stride), reduced later
-    int nprob, K, T, k_tiles, c_tiles, ntaps, split_rows, dbg;
+    int nprob, K, T, k_tiles, c_tiles, ntaps, split_rows;
     // grouped launches: chunks sorted by length (longest first), so that the short chunks of the small
     // pyramid levels fill the tail of the launch instead of opening a second round of full-length blocks
     int ub;                                     // XCD-local unit size in logical blocks (1: none)
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
             fill(step + 1);              // every table read of stages <= step happened before the last barrier
             __syncthreads();
         }
-        if (step + 1 < nsteps && !(L.dbg & 256)) issue(step + 1, buf ^ 1);
-        if (!(L.dbg & 512)) {
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        {
             const unsigned sb = lds0 + buf * STAGE_BYTES;
             s8v af[2][4], bf[2][4];
 #pragma unroll
@@ -458,7 +458,6 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
         L.nsorted = n;
     }
     L.dw = dw;
-    { const char* e = getenv("MI355_DBG"); if (e) L.dbg = atoi(e); }
     L.colsum = colsum;
     L.slab_stride = slab_stride;
     MI355_REQUIRE(slab_stride == 0 || chunks <= max_slabs, "conv_wgrad_slabs: %d slabs > workspace for %d", chunks, max_slabs);

@@ -677,8 +677,9 @@ class RetinaPlan(object):
         arena range [lo, hi)) the gradients in [lo, hi) are final".  Ranges are cut at top-level module
         boundaries (parameters() order is stem, stages, pyramid, heads; backward runs the other way), each
         at least `min_bytes` so that a collective stays xGMI-efficient."""
-        if getattr(self, '_segments', None) is not None:
-            return self._segments
+        cache = self.__dict__.setdefault('_segments', {})
+        if min_bytes in cache:
+            return cache[min_bytes]
         ready = {}
         for s in self.specs:
             end = getattr(s, '_wgrad_end', len(self.bwd_steps))
@@ -701,8 +702,8 @@ class RetinaPlan(object):
         for i in range(1, len(segs)):                 # execution order must be monotone
             segs[i][0] = max(segs[i][0], segs[i - 1][0])
         segs[-1][0] = len(self.bwd_steps)
-        self._segments = [tuple(x) for x in segs]
-        return self._segments
+        cache[min_bytes] = [tuple(x) for x in segs]
+        return cache[min_bytes]
 
     # ------------------------------------------------------------------ execution
     def _stream(self):
@@ -754,22 +755,41 @@ class RetinaPlan(object):
         self._bwd_pos = 0
         return arena
 
+    def _side_active(self):
+        return self.use_side and not torch.cuda.is_current_stream_capturing()
+
     def run_backward_segment(self, seg):
-        """Backward launches up to seg[0], then the parameter gradients of arena range [seg[1], seg[2])."""
+        """Backward launches up to seg[0], then the parameter gradients of arena range [seg[1], seg[2]).
+        With the side stream the table launch queues there behind this range's wgrads (stream order), i.e.
+        beside the data gradients of the layers still to come; `exchange_stream()` is then the stream on
+        which the range is final."""
         st = self._stream()
         arena = self.last_arena
         steps = self.bwd_steps if arena == 0 else self.bwd_steps_alt
         self._run(steps[self._bwd_pos:seg[0]], st)
         self._bwd_pos = seg[0]
-        self.join_side()
-        self._run_param_grads(arena, st, (seg[1], seg[2]))
+        if self._side_active() and self._side_dirty:
+            self._run_param_grads(arena, self._side.cuda_stream, (seg[1], seg[2]))
+        else:
+            self._run_param_grads(arena, st, (seg[1], seg[2]))
+
+    def exchange_stream(self):
+        """Stream on which the gradients of the last finished range are complete."""
+        if self._side_active() and self._side_dirty:
+            return self._side
+        return torch.cuda.current_stream(self.dev)
 
     def run_backward(self, g_cls, g_reg):
         arena = self.begin_backward(g_cls, g_reg)
         st = self._stream()
-        self._run(self.bwd_steps if arena == 0 else self.bwd_steps_alt, st)
-        self.join_side()
-        self._run_param_grads(arena, st)
+        if type(self)._build_backward is RetinaPlan._build_backward and self.pgrad_specs:
+            for seg in self.backward_segments():       # parameter-gradient tables ride the side stream
+                self.run_backward_segment(seg)
+            self.join_side()
+        else:
+            self._run(self.bwd_steps if arena == 0 else self.bwd_steps_alt, st)
+            self.join_side()
+            self._run_param_grads(arena, st)
         self._extra_param_grads(arena, st)
         return [self.grad_view(p, arena) if p.requires_grad else None for p in self.params]
 

@@ -109,7 +109,9 @@ class Trainer(object):
         works = []
         for seg in plan.backward_segments(self.segment_bytes):
             plan.run_backward_segment(seg)
-            works.append((self._allreduce_async(grad[seg[1]:seg[2]]), seg))
+            with torch.cuda.stream(plan.exchange_stream()):        # the collective waits for THAT stream
+                works.append((self._allreduce_async(grad[seg[1]:seg[2]]), seg))
+        plan.join_side()
         self._finish_exchange(plan, works)
         return plan, losses
 
