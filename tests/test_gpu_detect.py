@@ -170,3 +170,25 @@ def test_class_max_and_filter(dev):
     assert np.array_equal(lab.cpu().numpy(), rl.numpy().astype(np.int32))
     idx = ops_detect.score_filter(sc, 0.05)
     assert np.array_equal(idx.cpu().numpy(), np.nonzero(rs.numpy() > 0.05)[0].astype(np.int32))
+
+
+def test_batched_postprocess_golden(golden_dir, dev):
+    """utils/utils.py:76-114 (`postprocess`, batched decode + per-image NMS) against the reference's output
+    on the same head tensors, including an image without detections and the all-empty double-append quirk."""
+    from objectdetection.pytorch_amd.architectures.utils import BBoxTransform, ClipBoxes
+    from objectdetection.pytorch_amd.utils import utils as uu
+    g = np.load(os.path.join(golden_dir, 'postprocess.npz'))
+    H, W = (int(v) for v in g['hw'])
+    anc = torch.from_numpy(ref_cpu.anchors_for_image(H, W)).to(dev)
+    reg, cls = torch.from_numpy(g['reg']).to(dev), torch.from_numpy(g['cls']).to(dev)
+    x = torch.zeros(reg.shape[0], 3, H, W, device=dev)
+    out = uu.postprocess(x, anc, reg, cls, BBoxTransform(), ClipBoxes(), 0.05, 0.5)
+    assert len(out) == int(g['n_out'])
+    for i, o in enumerate(out):
+        assert o['scores'].shape == g['scores%d' % i].shape
+        np.testing.assert_array_equal(o['class_ids'], g['class_ids%d' % i])
+        np.testing.assert_array_equal(o['scores'], g['scores%d' % i])
+        if o['rois'].size:
+            np.testing.assert_allclose(o['rois'], g['rois%d' % i], rtol=1e-5, atol=1e-4)
+    out0 = uu.postprocess(x, anc, reg, cls * 0.01, BBoxTransform(), ClipBoxes(), 0.05, 0.5)
+    assert len(out0) == int(g['n_out_all_empty']) and all(o['scores'].size == 0 for o in out0)

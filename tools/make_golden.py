@@ -31,7 +31,8 @@ _tv = types.ModuleType('torchvision')
 _ops = types.ModuleType('torchvision.ops')
 
 
-def _nms_standin(boxes, scores, thr):
+def _nms_standin(boxes, scores, iou_threshold):
+    thr = iou_threshold
     return torch.from_numpy(ref_cpu.nms(boxes.detach().numpy(), scores.detach().numpy(), thr))
 
 
@@ -219,6 +220,31 @@ def gen_decode():
     print('decode: boxes', d['boxes'].shape)
 
 
+def gen_postprocess():
+    """Batched decode tail utils/utils.py:76-114 (f-4).  `cv2` is absent and only used by the image I/O
+    helpers of that module: an empty stand-in module lets it import."""
+    sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+    from utils import utils as ref_uu
+    H, W, B, C = 96, 128, 3, 6
+    anc = torch.from_numpy(ref_cpu.anchors_for_image(H, W))
+    A = anc.shape[1]
+    rng = np.random.default_rng(77)
+    reg = (rng.standard_normal((B, A, 4)) * 0.5).astype(np.float32)
+    cls = (rng.random((B, A, C)) ** 8).astype(np.float32) * 0.9       # few confident anchors
+    cls[2] *= 0.04                                                     # image 2: nothing over 0.05
+    x = torch.zeros(B, 3, H, W)
+    out = ref_uu.postprocess(x, anc, torch.from_numpy(reg), torch.from_numpy(cls), ref_utils.BBoxTransform(),
+                             ref_utils.ClipBoxes(), 0.05, 0.5)
+    d = dict(hw=np.array([H, W]), reg=reg, cls=cls, n_out=np.array(len(out)))
+    for i, o in enumerate(out):
+        d['rois%d' % i], d['class_ids%d' % i], d['scores%d' % i] = o['rois'], o['class_ids'], o['scores']
+    out0 = ref_uu.postprocess(x, anc, torch.from_numpy(reg), torch.from_numpy(cls * 0.01), ref_utils.BBoxTransform(),
+                              ref_utils.ClipBoxes(), 0.05, 0.5)
+    d['n_out_all_empty'] = np.array(len(out0))                         # the double-append quirk (:83-88)
+    np.savez_compressed(os.path.join(OUT, 'postprocess.npz'), **d)
+    print('postprocess: images', len(out), [o['scores'].shape for o in out], 'all-empty list length', len(out0))
+
+
 # ---------------------------------------------------------------- end to end RetinaNet (a-1..a-4)
 def load_synth(model, depth, num_classes, gain):
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -401,13 +427,15 @@ def gen_e2e_effdet(coef, H, W, B, num_classes, tag, gain, head_std):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['anchors', 'loss', 'decode', 'e2e', 'effdet', 'variants']
+    which = sys.argv[1:] or ['anchors', 'loss', 'decode', 'e2e', 'effdet', 'variants', 'postprocess']
     if 'anchors' in which:
         gen_anchors()
     if 'loss' in which:
         gen_loss()
     if 'decode' in which:
         gen_decode()
+    if 'postprocess' in which:
+        gen_postprocess()
     if 'variants' in which:
         gen_e2e_variant('tiny', 64, 96, 2, 12, 'tiny_64x96', 0.9)
         gen_e2e_variant('p45p6', 192, 288, 1, 12, 'p45p6_192x288', 0.87)
