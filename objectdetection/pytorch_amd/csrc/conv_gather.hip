@@ -710,7 +710,13 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         big_tiles += cdiv((long long)in.prob[i].N * in.prob[i].P * in.prob[i].Q, 256);
         grid128 += cdiv((long long)in.prob[i].N * in.prob[i].P * in.prob[i].Q, 128) * cdiv(in.K, BN);
     }
-    const bool single = max_ksteps <= 2 && ksplit <= 1;
+    // One stage (33 KiB of LDS, 3 blocks = 12 waves per CU) also wins for LONG reductions once the launch has
+    // at least three 128x128 tiles per CU: measured on the head tower convs 1010 TFLOP/s against 920 for the
+    // double-buffered form (2 blocks per CU) and 980 for the row-of-taps kernel; resident waves, not the
+    // depth of one block's pipeline, hide the LDS-DMA latency.
+    static const int single_min_grid = [] { const char* e = getenv("MI355_SINGLE_MIN_GRID"); return e ? atoi(e) : 768; }();
+    const bool many = single_min_grid > 0 && grid128 >= single_min_grid && ksplit <= 1;
+    const bool single = (max_ksteps <= 2 || many) && ksplit <= 1;
     static const int big_min_grid = [] {
         const char* e = getenv("MI355_GATHER_BIG");
         return e ? atoi(e) : 256;
@@ -720,7 +726,7 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         return e ? atoi(e) : 2;
     }();
     const bool splitk = ksplit > 1;
-    bool row3 = !flat && row3_mode > 0 && !splitk;     // 3x3 / stride 1 / same: column taps share a staging
+    bool row3 = !flat && row3_mode > 0 && !splitk && !many;   // 3x3 / stride 1 / same: column taps share a staging
     for (int i = 0; i < in.nprob && row3; ++i) {
         const Mi355ConvProblem& s = in.prob[i];
         // (data gradients walk the taps downwards: dw0 = +1, dws = -1; canonicalised below)
@@ -733,7 +739,7 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     }();
     if (deep_over_row3 && grid128 <= deep_over_row3) row3 = false;
     const bool row3_big = row3 && row3_mode == 4;
-    const bool big = !row3 && !splitk && !flat && max_ksteps >= 6 && big_min_grid > 0 &&
+    const bool big = !row3 && !splitk && !single && !flat && max_ksteps >= 6 && big_min_grid > 0 &&
                      big_tiles * cdiv(in.K, BN) >= big_min_grid;
     const int BM = (big || row3_big) ? 256 : 128;
     for (int i = 0; i < in.nprob; ++i) {
@@ -825,13 +831,13 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     if (row3) {
         if (row3_big) hipLaunchKernelGGL((conv_gather_row3_kernel<4>), g, dim3(512), ROW3_LDS4, st, L);
         else          hipLaunchKernelGGL((conv_gather_row3_kernel<2>), g, dim3(256), ROW3_LDS2, st, L);
+    } else if (single) {
+        if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
+        else      hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
     } else if (big) {
         hipLaunchKernelGGL((conv_gather_kernel<false, 3, 4>), g, dim3(512), 3 * STAGE3, st, L);
     } else if (deep) {
         hipLaunchKernelGGL((conv_gather_kernel<false, 4, 2>), g, dim3(256), 4 * STAGE2, st, L);
-    } else if (single) {
-        if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
-        else      hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
     } else {
         if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 2, 2>), g, dim3(256), 2 * STAGE2, st, L);
         else      hipLaunchKernelGGL((conv_gather_kernel<false, 2, 2>), g, dim3(256), 2 * STAGE2, st, L);

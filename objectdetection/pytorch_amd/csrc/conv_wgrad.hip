@@ -342,6 +342,242 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// ROW3 weight gradient: 3x3 / stride 1 / "same" convs with C % 64 == 0 and image width W | 64.
+// A block owns ONE kernel row r, 128 output channels and 64 input channels, and accumulates the three
+// column taps at once: the dy tile (64 pixels x 128 k) is staged once for the three taps and the
+// activation tile once, two rows longer (66 x 64 channels); tap s reads it shifted by s rows through
+// ds_read_b64_tr_b16 (pixels whose column q + s - 1 leaves the image read the zero row).  Per 64-pixel
+// stage that is 25 KiB of LDS-DMA for 3 x (128 x 64 x 64) MACs instead of 3 x 32 KiB: the generic
+// kernel's dominant cost (vector-memory issue + L2->LDS traffic, and the 8-XCD re-fetch of the rows).
+// LDS image of the activation tile: 128-B rows, 16-B chunk c at position c ^ (gx(row) << 1),
+// gx(row) = bit1(row) | bit3(row) << 1: the 8 rows of a 32-lane half of a transposed read (any of the
+// three shifts) land in 8 distinct 32-B bank groups.
+constexpr int R3_TC = 64, R3_XROWS = 72, R3_DY_BYTES = RM * TK * 2, R3_X_BYTES = R3_XROWS * R3_TC * 2;
+constexpr int R3_STAGE = 26624;                           // 16384 + 9216, 1 KiB aligned
+constexpr int R3_TABN = 520, R3_TAB_OFF = 2 * R3_STAGE;
+constexpr int R3_EPI_LD = R3_TC + 4;
+constexpr int R3_LDS = (R3_TAB_OFF + R3_TABN * 16 > TK * R3_EPI_LD * 4) ? R3_TAB_OFF + R3_TABN * 16 : TK * R3_EPI_LD * 4;
+
+__device__ __forceinline__ int r3_gx(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int b = blockIdx.x;
+    const int c_tile = b % L.c_tiles;  b /= L.c_tiles;
+    const int k_tile = b % L.k_tiles;  b /= L.k_tiles;
+    const int kr = b % 3;              b /= 3;          // kernel row of this block
+    const int chunk = b;
+
+    WProb P = L.p[0];
+    int m_begin;
+    if (L.nsorted > 0) {
+        const int pi = L.ch_prob[chunk];
+#pragma unroll
+        for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
+            if (i == pi) P = L.p[i];
+        m_begin = L.ch_mbegin[chunk];
+    } else {
+#pragma unroll
+        for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
+            if (i < L.nprob && chunk >= L.p[i].chunk_begin) P = L.p[i];
+        m_begin = (chunk - P.chunk_begin) * L.split_rows;
+    }
+    const int m_end = min(P.M, m_begin + L.split_rows);
+    const int k0 = k_tile * TK, c0 = c_tile * R3_TC;
+    const int dh = P.dh0 + kr;                          // (dhs == 1)
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(P.in, (unsigned)P.in_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(P.dy, (unsigned)P.dy_bytes);
+
+    // dy staging as in the generic kernel: row = tid/16 + 16 i, slot = tid%16, logical chunk slot ^ (f << 1)
+    const int srow = tid >> 4, slot = tid & 15;
+    const int fsw = ((srow & 3) | (((srow >> 3) & 1) << 2)) << 1;
+    const int ky = k0 + (slot ^ fsw) * 8;
+    const bool ky_ok = ky + 8 <= L.K;
+    // activation staging: row j = tid/8 + 32 i (i = 0, 1; wave 0 also j = 64 + tid/8), slot = tid%8
+    const int xrow = tid >> 3, xslot = tid & 7;
+    const int cx = c0 + ((xslot ^ (r3_gx(xrow) << 1)) << 3);    // gx(xrow + 32 i) == gx(xrow); rows 64.. below
+    const int cx64 = c0 + ((xslot ^ (r3_gx(64 + xrow) << 1)) << 3);
+
+    // pixel-row table, entry e + 1 <-> pixel m_begin + 64 * step0 + e, e = -1 .. 518:
+    //   .x = element offset of input pixel (n, p, q)   .y = p (or far out of range)   .z = dy row offset / -1
+    int4* tab = reinterpret_cast<int4*>(smem + R3_TAB_OFF);
+    auto fill = [&](int step0) {
+        for (int e = tid; e < R3_TABN; e += 256) {
+            const int m = m_begin + step0 * RM + e - 1;
+            int4 t = make_int4(0, -0x40000000, -1, 0);
+            if (m >= 0 && m < P.M) {
+                const unsigned n = fdiv((unsigned)m, P.dPQ);
+                const unsigned rem = (unsigned)m - n * (unsigned)(P.P * P.Q);
+                const unsigned p = fdiv(rem, P.dQ);
+                const unsigned q = rem - p * (unsigned)P.Q;
+                t.x = (int)n * P.in_sN + ((int)p * P.W + (int)q) * P.C;
+                t.y = (int)p;
+                if (m < m_end && e >= 1) t.z = (int)n * P.dy_sN + (int)rem * L.K;
+            }
+            tab[e] = t;
+        }
+    };
+    const int xdelta = dh * P.W * P.C;
+    auto issue = [&](int step, int buf) {
+        unsigned char* sy = smem + buf * R3_STAGE;
+        unsigned char* sx = sy + R3_DY_BYTES;
+        const int tb = (step & 7) * RM;
+        int4 ty[4], tx[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ty[i] = tab[tb + srow + 16 * i + 1];            // before any DMA
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tx[i] = tab[min(tb + xrow + 32 * i, R3_TABN - 1)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned offy = (ky_ok && ty[i].z >= 0) ? (unsigned)(ty[i].z + ky) * 2u : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (LDS_PTR(void))(sy + (i * 256 + wv * 64) * 16),
+                                                     16, offy, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i < 2 || wv == 0) {                                     // rows 64..71: wave 0 only
+                const int j = xrow + 32 * i;
+                const bool ok = j < RM + 2 && (unsigned)(tx[i].y + dh) < (unsigned)P.H;
+                const unsigned offx = ok ? (unsigned)(tx[i].x + xdelta + (i < 2 ? cx : cx64)) * 2u : OOB_OFFSET;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_PTR(void))(sx + (i * 256 + wv * 64) * 16),
+                                                         16, offx, 0, 0, 0);
+            }
+        }
+    };
+
+    f4v acc[3][4][2];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[s3][i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+
+    const int wk = wv >> 1, wc = wv & 1;
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int f = (q4 | ((g & 1) << 2)) << 1;
+    const int row_lo = 8 * g + q4;
+    const int half8 = (p4 & 1) * 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)(LDS_PTR(void))smem;
+    unsigned ady[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ady[t] = row_lo * 256 + ((8 * wk + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
+    // activation fragment addresses: [sub][h][shift][t]; pixel i = 32 sub + row_lo + 4 h reads staged row i + s;
+    // W | 64 and chunks start at multiples of 64, so the image column of pixel i is i mod W
+    constexpr unsigned ZROW = R3_DY_BYTES + (R3_XROWS - 1) * 128;       // staged row 71: always zeros
+    unsigned adx[2][2][3][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = sub * 32 + row_lo + 4 * h;
+            const int q = i & (P.W - 1);
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int row = i + s3;
+                const bool edge = (s3 == 0 && q == 0) || (s3 == 2 && q == P.W - 1);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int lc = 4 * wc + 2 * t + (p4 >> 1);
+                    adx[sub][h][s3][t] = edge ? ZROW + half8
+                                              : R3_DY_BYTES + row * 128 + ((lc ^ (r3_gx(row) << 1)) << 4) + half8;
+                }
+            }
+        }
+
+    const bool do_colsum = L.colsum != nullptr && c_tile == 0 && kr == 0 && wc == 0;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nsteps = (m_end - m_begin + RM - 1) / RM;
+    fill(0);
+    __syncthreads();
+    if (nsteps > 0) issue(0, 0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (((step + 1) & 7) == 0 && step + 1 < nsteps) {
+            fill(step + 1);
+            __syncthreads();
+        }
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        const unsigned sb = lds0 + buf * R3_STAGE;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            s8v af[4], bf[3][2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const unsigned a = sb + ady[t] + sub * 8192;
+                const s4v a0 = lds_tr<0>(a), a1 = lds_tr<1024>(a);
+                af[t] = (s8v){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            }
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const s4v b0 = lds_tr<0>(sb + adx[sub][0][s3][t]), b1 = lds_tr<0>(sb + adx[sub][1][s3][t]);
+                    bf[s3][t] = (s8v){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                }
+            lds_wait();
+            if (do_colsum) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) csum[t] += bf16_to_f32((unsigned short)af[t][e]);
+            }
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[s3][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[s3][j], acc[s3][i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    if (do_colsum) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v = csum[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int k = k0 + wk * 64 + t * 16 + (lane & 15);
+            if (lane < 16 && k < L.K) {
+                if (L.slab_stride > 0) L.colsum[(long long)chunk * L.K + k] = v;
+                else atomicAdd(L.colsum + k, v);
+            }
+        }
+    }
+    // ---- epilogue, one column tap at a time through LDS: 256-B contiguous row segments
+    float* epi = reinterpret_cast<float*>(smem);
+    const int fr = lane & 15, fq = lane >> 4;
+    const long long wrow = (long long)L.T * P.C;
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    epi[(wk * 64 + i * 16 + fq * 4 + r) * R3_EPI_LD + wc * 32 + j * 16 + fr] = acc[s3][i][j][r];
+        __syncthreads();
+        const long long coff = (long long)((P.r0 + kr * P.rs) * P.S + (P.s0 + s3 * P.ss)) * P.C + c0 + lane;
+        for (int rr = wv; rr < TK; rr += 4) {
+            const int k = k0 + rr;
+            if (k >= L.K) break;
+            float* dst = L.dw + k * wrow + coff;
+            const float v = epi[rr * R3_EPI_LD + lane];
+            if (L.slab_stride > 0) dst[(long long)chunk * L.slab_stride] = v;
+            else atomicAdd(dst, v);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 template <bool ALIGNED>
@@ -440,6 +676,17 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
         chunks += (int)cdiv(M, split_rows);
     }
     if (ntaps == 0) return MI355_OK;
+    // row-of-taps kernel: 3x3 / stride 1 / same, C % 64 == 0, image width a power of two <= 64
+    static const int row3_on = [] {
+        const char* e = getenv("MI355_WG_ROW3");
+        return e ? atoi(e) : 1;
+    }();
+    bool row3 = row3_on && C % 64 == 0 && ntaps == 9;
+    for (int i = 0; i < in.nprob && row3; ++i) {
+        const Mi355ConvProblem& q = in.prob[i];
+        row3 = q.TR == 3 && q.TS == 3 && q.sh == 1 && q.sw == 1 && q.dhs == 1 && q.dws == 1 && q.dw0 == -1 &&
+               q.Q == q.W && q.W <= 64 && (q.W & (q.W - 1)) == 0;
+    }
     if (in.nprob > 1 && chunks <= MAX_SORTED) {
         int n = 0, rows[MAX_SORTED];
         for (int i = 0; i < in.nprob; ++i)
@@ -462,10 +709,14 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
     L.slab_stride = slab_stride;
     MI355_REQUIRE(slab_stride == 0 || chunks <= max_slabs, "conv_wgrad_slabs: %d slabs > workspace for %d", chunks, max_slabs);
     L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.ntaps = ntaps; L.split_rows = split_rows;
-    const bool flat = C < TC;
+    const bool flat = C < TC && !row3;
     L.k_tiles = (int)cdiv(in.K, TK);
     L.c_tiles = flat ? (int)cdiv((long long)ntaps * C, TC) : (int)cdiv(C, TC);
     if (flat) L.ntaps = 1;
+    if (row3) {
+        L.c_tiles = C / R3_TC;
+        L.ntaps = 3;                                   // kernel rows; a block accumulates the three column taps
+    }
     const long long grid = (long long)chunks * L.ntaps * L.k_tiles * L.c_tiles;
     MI355_REQUIRE(grid > 0 && grid < 0x7fffffffLL, "conv_wgrad: grid");
     static const int unit_mode = [] {
@@ -473,7 +724,7 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
         return e ? atoi(e) : 1;
     }();
     L.ub = 1;
-    if (unit_mode && in.nprob == 1) {                  // equal chunks (but the last): balanced iff #units % 8 == 0
+    if (unit_mode && in.nprob == 1 && !row3) {                  // equal chunks (but the last): balanced iff #units % 8 == 0
         const int tpc = L.ntaps * L.k_tiles * L.c_tiles;
         const int cand[2] = {tpc, L.k_tiles * L.c_tiles};      // whole chunk, or one tap's tiles of a chunk
         for (int i = 0; i < 2; ++i)
@@ -489,7 +740,14 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
     }
     const dim3 g((unsigned)grid);
     hipStream_t st = (hipStream_t)stream;
-    if (two) {
+    if (row3) {
+        static bool r3_attr = false;
+        if (!r3_attr) {
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
+            r3_attr = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_row3_kernel, g, dim3(256), R3_LDS, st, L);
+    } else if (two) {
         if (flat) hipLaunchKernelGGL((conv_wgrad_kernel<true, 2>), g, dim3(512), lds_bytes(2), st, L);
         else      hipLaunchKernelGGL((conv_wgrad_kernel<false, 2>), g, dim3(512), lds_bytes(2), st, L);
     } else {

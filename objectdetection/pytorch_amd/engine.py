@@ -340,7 +340,7 @@ class RetinaPlan(object):
             L.prob[j] = pr
         L.nprob, L.K, L.T = len(problems), spec.Kpad, spec.T
         slab = spec.Kpad * spec.T * spec.Cpad
-        tiles = ops_conv.wgrad_tiles(spec.Kpad, spec.Cpad, spec.T)
+        tiles = ops_conv.wgrad_tiles(spec.Kpad, spec.Cpad, spec.T, problems)
         split = pick_split_rows(rows, tiles, target_blocks=int(os.environ.get('MI355_WG_BLOCKS', '512')),
                                 min_rows=int(os.environ.get('MI355_WG_MINROWS', '512')),
                                 granule=int(os.environ.get('MI355_WG_GRANULE', '64')))

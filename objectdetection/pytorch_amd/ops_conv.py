@@ -142,9 +142,20 @@ def launch_wgrad(problems, K, T, dw, split_rows, stream_tensor, colsum=None):
          stream_of(stream_tensor))
 
 
-def wgrad_tiles(kpad, cpad, taps):
+def wgrad_row3_ok(problems, cpad):
+    """Launch takes the row-of-taps wgrad kernel (mirrors the host check in conv_wgrad.hip)."""
+    import os
+    if os.environ.get('MI355_WG_ROW3', '1') == '0' or cpad % 64:
+        return False
+    return all(p.TR == 3 and p.TS == 3 and p.sh == 1 and p.sw == 1 and p.dhs == 1 and p.dws == 1 and p.dw0 == -1
+               and p.Q == p.W and p.W <= 64 and (p.W & (p.W - 1)) == 0 for p in problems)
+
+
+def wgrad_tiles(kpad, cpad, taps, problems=None):
     """Output tiles of one pixel chunk of the wgrad launch (mirrors conv_wgrad.hip)."""
     kt = -(-kpad // 128)
+    if problems is not None and taps == 9 and wgrad_row3_ok(problems, cpad):
+        return kt * 3 * (cpad // 64)
     return kt * (-(-taps * cpad // 128)) if cpad < 128 else kt * taps * (-(-cpad // 128))
 
 

@@ -189,6 +189,25 @@ def test_conv_wgrad(dev, case):
             assert float(G[K:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('case', [(3, 5, 16, 64, 64, 3, 1, 1), (1, 3, 64, 128, 136, 3, 1, 1), (2, 32, 32, 64, 256, 3, 1, 1),
+                                  (5, 4, 4, 256, 40, 3, 1, 1), (2, 7, 8, 192, 128, 3, 1, 1)])
+def test_conv_wgrad_row_of_taps(dev, case):
+    """3x3 / stride 1 / same with a power-of-two width: the kernel that stages dy and the activation rows once
+    per kernel row (conv_wgrad_row3_kernel), images that are not multiples of the 64-pixel stage, several
+    images per stage, chunk splits, and the fp32-atomic as well as the slab output."""
+    test_conv_wgrad(dev, case)
+    from objectdetection.pytorch_amd import ops_conv
+    N, H, W, C, K, R, stride, pad = case
+    x, dy = _mk((N, C, H, W), 11), _mk((N, K, H, W), 12)
+    ref = torch.nn.grad.conv2d_weight(x, (K, C, R, R), dy, stride, pad)
+    kpad = (K + 7) // 8 * 8
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    dyh = torch.zeros((N, H, W, kpad), dtype=torch.bfloat16, device=dev)
+    dyh[..., :K] = dy.permute(0, 2, 3, 1).to(dev).to(torch.bfloat16)
+    G = ops_conv.conv_wgrad(xh, dyh, R, R, stride, pad, split_rows=128)
+    _close(G[:K].reshape(K, R, R, C).permute(0, 3, 1, 2), ref, 2e-3)
+
+
 def test_grouped_heads_shared_weights(dev):
     """Five pyramid levels, one launch, outputs concatenated along A (retinanet.py:285-287)."""
     from objectdetection.pytorch_amd import ops_conv
