@@ -65,7 +65,8 @@ __device__ __forceinline__ float activate(float v, int act) {
 // Accumulators hold the TRANSPOSED tile: acc[i][j][r] = out[pixel i*16+fr][channel j*16+fq*4+r]
 // (weights are the MFMA A operand), so a lane owns 4 consecutive channels of one pixel and the
 // epilogue stages with 8/16-B LDS writes.  The bias is the accumulator's initial value.
-__device__ __forceinline__ void init_acc(f4v (&acc)[4][4], const LaunchDev& L, int n0, int wn, int fq) {
+template <int TA = 4>
+__device__ __forceinline__ void init_acc(f4v (&acc)[TA][4], const LaunchDev& L, int n0, int wn, int fq) {
     {
         f4v b4[4];
 #pragma unroll
@@ -91,21 +92,25 @@ __device__ __forceinline__ void init_acc(f4v (&acc)[4][4], const LaunchDev& L, i
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = b4[j];
+            for (int i = 0; i < TA; ++i) acc[i][j] = b4[j];
     }
 }
 
 // Epilogue through LDS: bias is already in the accumulators; addend / activation / ReLU-backward mask,
 // 16-B coalesced row stores.
-template <int WM>
-__device__ __forceinline__ void gather_epilogue(f4v (&acc)[4][4], const LaunchDev& L, const ProbDev& P,
+// TA = 16-row accumulator fragments per wave: 4 (64x64 per wave, 2 wave columns, 128-wide tile) or 2
+// (32x64 per wave, 4 wave rows, 64-wide tile: K <= 64 layers without empty wave columns).
+template <int WM, int TA = 4>
+__device__ __forceinline__ void gather_epilogue(f4v (&acc)[TA][4], const LaunchDev& L, const ProbDev& P,
                                                 unsigned char* smem, const long long* s_outoff,
                                                 const long long* s_addoff, int n0) {
-    constexpr int NTHREADS = WM * 128;
+    constexpr int NTHREADS = WM * 128, BM = WM * 64, BNT = TA == 4 ? 128 : 64;
+    constexpr int CT = BNT / 8, RP = NTHREADS / CT;    // threads per output row, rows per read pass
+    constexpr int LD16 = BNT + 4, LD32 = BNT + 4;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
+    const int wrow0 = TA == 4 ? (wv >> 1) * 64 : wv * 32, wn = TA == 4 ? (wv & 1) : 0;
     const int fr = lane & 15, fq = lane >> 4;
-    const int col = (tid & 15) * 8;
+    const int col = (tid % CT) * 8;
     const int k0 = n0 + col;
     const int nvalid = min(8, L.K - k0);
     const bool full = nvalid == 8;
@@ -115,31 +120,32 @@ __device__ __forceinline__ void gather_epilogue(f4v (&acc)[4][4], const LaunchDe
         // FAST: activation in registers, bf16 staging of the whole tile (one barrier), the read
         // side is a 16-B copy (+ the ReLU-backward mask as a bit select).
         unsigned short* st16 = reinterpret_cast<unsigned short*>(smem);
-        long long oo[8];
-        s8v mk[8];
+        constexpr int NP = BM / RP;
+        long long oo[NP];
+        s8v mk[NP];
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {       // mask reads first: latency hides under staging
-            const int row = pass * (NTHREADS / 16) + (tid >> 4);
+        for (int pass = 0; pass < NP; ++pass) {      // mask reads first: latency hides under staging
+            const int row = pass * RP + tid / CT;
             oo[pass] = k0 < L.K ? s_outoff[row] : -1;
             mk[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
             if (P.mask && oo[pass] >= 0) mk[pass] = *reinterpret_cast<const s8v*>(P.mask + oo[pass] + k0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TA; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 s4v pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = (short)f32_to_bf16_rn(activate(acc[i][j][r], L.act));
-                *reinterpret_cast<s4v*>(st16 + (wm * 64 + i * 16 + fr) * EPI16_LD + wn * 64 + j * 16 + fq * 4) = pk;
+                *reinterpret_cast<s4v*>(st16 + (wrow0 + i * 16 + fr) * LD16 + wn * 64 + j * 16 + fq * 4) = pk;
             }
         __syncthreads();
 #pragma unroll
-        for (int pass = 0; pass < 8; ++pass) {
+        for (int pass = 0; pass < NP; ++pass) {
             if (oo[pass] < 0) continue;
-            const int row = pass * (NTHREADS / 16) + (tid >> 4);
-            const s4v lo = *reinterpret_cast<const s4v*>(st16 + row * EPI16_LD + col);
-            const s4v hi = *reinterpret_cast<const s4v*>(st16 + row * EPI16_LD + col + 4);
+            const int row = pass * RP + tid / CT;
+            const s4v lo = *reinterpret_cast<const s4v*>(st16 + row * LD16 + col);
+            const s4v hi = *reinterpret_cast<const s4v*>(st16 + row * LD16 + col + 4);
             s8v o = (s8v){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             if (P.mask) {
 #pragma unroll
@@ -152,13 +158,13 @@ __device__ __forceinline__ void gather_epilogue(f4v (&acc)[4][4], const LaunchDe
     }
     // GENERAL: fp32 staging in two 64-row halves (addend / fp32 output / ragged channel tails)
     float* epi = reinterpret_cast<float*>(smem);
-    constexpr int PH = 64 / (NTHREADS / 16);           // read passes per 64-row slice
+    constexpr int PH = 64 / RP;                        // read passes per 64-row slice
     for (int half = 0; half < WM; ++half) {
         long long oo[PH];
         s8v mk[PH], ad[PH];
 #pragma unroll
         for (int pass = 0; pass < PH; ++pass) {
-            const int row = half * 64 + pass * (NTHREADS / 16) + (tid >> 4);
+            const int row = half * 64 + pass * RP + tid / CT;
             oo[pass] = k0 < L.K ? s_outoff[row] : -1;
             mk[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
             ad[pass] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
@@ -167,20 +173,20 @@ __device__ __forceinline__ void gather_epilogue(f4v (&acc)[4][4], const LaunchDe
                 if (P.addend) ad[pass] = *reinterpret_cast<const s8v*>(P.addend + s_addoff[row] + k0);
             }
         }
-        if (wm == half) {
+        if (wrow0 / 64 == half) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TA; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<f4v*>(epi + (i * 16 + fr) * EPI_LD + wn * 64 + j * 16 + fq * 4) = acc[i][j];
+                    *reinterpret_cast<f4v*>(epi + (wrow0 % 64 + i * 16 + fr) * LD32 + wn * 64 + j * 16 + fq * 4) = acc[i][j];
         }
         __syncthreads();
 #pragma unroll
         for (int pass = 0; pass < PH; ++pass) {
             if (oo[pass] < 0) continue;
-            const int hrow = pass * (NTHREADS / 16) + (tid >> 4);
-            const f4v v0 = *reinterpret_cast<const f4v*>(epi + hrow * EPI_LD + col);
-            const f4v v1 = *reinterpret_cast<const f4v*>(epi + hrow * EPI_LD + col + 4);
+            const int hrow = pass * RP + tid / CT;
+            const f4v v0 = *reinterpret_cast<const f4v*>(epi + hrow * LD32 + col);
+            const f4v v1 = *reinterpret_cast<const f4v*>(epi + hrow * LD32 + col + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             if (full) {
                 if (P.mask && mask_first) {
@@ -233,11 +239,14 @@ __device__ __forceinline__ void gather_epilogue(f4v (&acc)[4][4], const LaunchDe
 // <WM 4, STAGES 3>: 256x128, 8 waves, 1 block/CU, THREE stages with a counted `s_waitcnt vmcnt` and a
 //                   raw s_barrier: the LDS-DMA of k-steps t+1 and t+2 stays in flight across the barrier
 //                   of k-step t (cdna_hip_programming.md §5 "Pipelining across barriers").
-template <bool FLAT, int STAGES, int WM>
-__global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDev L) {
-    constexpr int NTHREADS = WM * 128, BM = WM * 64;
-    constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = A_BYTES + BN * BK * 2;
-    constexpr int NB = 1024 / NTHREADS;               // B-tile DMA instructions per thread and stage
+// <.., TA 2>:       128x64 tile, four wave rows of 32x64 accumulators (half the registers: up to 5 blocks per
+//                   CU): layers with K <= 64 (stem, layer1, box output) without an empty wave column.
+template <bool FLAT, int STAGES, int WM, int TA = 4>
+__global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(const LaunchDev L) {
+    static_assert(TA == 4 || WM == 2, "narrow tile: 4 waves");
+    constexpr int NTHREADS = WM * 128, BM = WM * 64, BNT = TA == 4 ? 128 : 64;
+    constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = A_BYTES + BNT * BK * 2;
+    constexpr int NB = BNT * 8 / NTHREADS;            // B-tile DMA instructions per thread and stage
     constexpr int ROWSTEP = NTHREADS / 8;             // rows covered by one DMA instruction of the block
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ long long s_outoff[BM];
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
     ProbDev P = L.p[pi];                                 // one block copy out of the kernarg segment
     if (L.ksplit > 1) P.out = reinterpret_cast<float*>(P.out) + split * L.split_stride;
     const int m0 = (m_tile - P.tile_begin) * BM;
-    const int n0 = n_tile * BN;
+    const int n0 = n_tile * BNT;
     const int PQ = P.P * P.Q;
 
     // ---- per-row output / addend offsets (used by the epilogue)
@@ -359,12 +368,12 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
         }
     };
 
-    const int wm = wv >> 1, wn = wv & 1;
+    const int wrow0 = TA == 4 ? (wv >> 1) * 64 : wv * 32, wn = TA == 4 ? (wv & 1) : 0;
     const int fr = lane & 15, fq = lane >> 4;
-    f4v acc[4][4];
+    f4v acc[TA][4];
     // ds_read_b128 byte offsets of this lane's fragments inside a stage (row r, chunk c):
     //   r*128 + ((c ^ (r & 7)) << 4); r & 7 == fr & 7 for every 16-row tile.
-    const int a_rd = (wm * 64 + fr) * 128;
+    const int a_rd = (wrow0 + fr) * 128;
     const int b_rd = A_BYTES + (wn * 64 + fr) * 128;
     const int sw0 = ((fq) ^ (fr & 7)) << 4;           // k-sub 0: chunk fq
     const int sw1 = ((4 + fq) ^ (fr & 7)) << 4;       // k-sub 1: chunk 4 + fq
@@ -374,14 +383,14 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int sw = sub ? sw1 : sw0;
-            s8v af[4], bf[4];
+            s8v af[TA], bf[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                af[t] = *reinterpret_cast<const s8v*>(st + a_rd + t * 16 * 128 + sw);
+                if (t < TA) af[t] = *reinterpret_cast<const s8v*>(st + a_rd + t * 16 * 128 + sw);
                 bf[t] = *reinterpret_cast<const s8v*>(st + b_rd + t * 16 * 128 + sw);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TA; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
     };
     if (ksteps > 0) issue(0, 0);
     // (bias loads are issued behind the first stage's DMA so that both latencies overlap)
-    init_acc(acc, L, n0, wn, fq);
+    init_acc<TA>(acc, L, n0, wn, fq);
     if (STAGES >= 3) {
         // ring of STAGES buffers: stage ks is read while the next STAGES - 2 are in flight.  Per thread a
         // stage is 4 + NB DMA instructions, so `vmcnt(r * (4 + NB))` retires stage ks and leaves the r
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_kernel(const LaunchDe
         }
     }
 
-    gather_epilogue<WM>(acc, L, P, smem, s_outoff, s_addoff, n0);
+    gather_epilogue<WM, TA>(acc, L, P, smem, s_outoff, s_addoff, n0);
 }
 
 
@@ -710,6 +719,13 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         big_tiles += cdiv((long long)in.prob[i].N * in.prob[i].P * in.prob[i].Q, 256);
         grid128 += cdiv((long long)in.prob[i].N * in.prob[i].P * in.prob[i].Q, 128) * cdiv(in.K, BN);
     }
+    // 128x64 tiles (four wave rows) for layers with at most 64 output channels: no empty wave column
+    static const int narrow_mode = [] {
+        const char* e = getenv("MI355_NARROW");
+        return e ? atoi(e) : 1;                        // 0 off, 1 K <= 64, 2 every launch (experiments)
+    }();
+    const bool narrow = ksplit <= 1 && ((narrow_mode == 1 && in.K <= 64) || narrow_mode == 2);
+    if (narrow) grid128 = grid128 / cdiv(in.K, BN) * cdiv(in.K, 64);
     // One stage (33 KiB of LDS, 3 blocks = 12 waves per CU) also wins for LONG reductions once the launch has
     // at least three 128x128 tiles per CU: measured on the head tower convs 1010 TFLOP/s against 920 for the
     // double-buffered form (2 blocks per CU) and 980 for the row-of-taps kernel; resident waves, not the
@@ -726,7 +742,7 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         return e ? atoi(e) : 2;
     }();
     const bool splitk = ksplit > 1;
-    bool row3 = !flat && row3_mode > 0 && !splitk && !many;   // 3x3 / stride 1 / same: column taps share a staging
+    bool row3 = !flat && row3_mode > 0 && !splitk && !many && !narrow;   // 3x3 / stride 1 / same: column taps share a staging
     for (int i = 0; i < in.nprob && row3; ++i) {
         const Mi355ConvProblem& s = in.prob[i];
         // (data gradients walk the taps downwards: dw0 = +1, dws = -1; canonicalised below)
@@ -739,7 +755,7 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     }();
     if (deep_over_row3 && grid128 <= deep_over_row3) row3 = false;
     const bool row3_big = row3 && row3_mode == 4;
-    const bool big = !row3 && !splitk && !single && !flat && max_ksteps >= 6 && big_min_grid > 0 &&
+    const bool big = !row3 && !splitk && !single && !narrow && !flat && max_ksteps >= 6 && big_min_grid > 0 &&
                      big_tiles * cdiv(in.K, BN) >= big_min_grid;
     const int BM = (big || row3_big) ? 256 : 128;
     for (int i = 0; i < in.nprob; ++i) {
@@ -780,7 +796,7 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     L.w = (const unsigned short*)in.weight;
     L.bias = in.bias;
     L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.act = in.act; L.out_f32 = in.out_f32; L.flags = in.flags;
-    L.n_tiles = (int)cdiv(in.K, BN);
+    L.n_tiles = (int)cdiv(in.K, narrow ? 64 : BN);
     L.w_bytes = (int)w_bytes;
     long long grid = (long long)tiles * L.n_tiles;
     MI355_REQUIRE(grid > 0 && grid < 0x7fffffffLL, "conv_gather: grid");
@@ -825,10 +841,25 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         const char* e = getenv("MI355_GATHER_DEEP");
         return e ? atoi(e) : 288;
     }();
-    const bool deep = !flat && !big && !row3 && max_ksteps >= 6 && grid <= deep_max_grid;
+    const bool deep = !flat && !big && !row3 && !narrow && max_ksteps >= 6 && grid <= deep_max_grid;
     const dim3 g((unsigned)grid);
     hipStream_t st = (hipStream_t)stream;
-    if (row3) {
+    if (narrow) {
+        constexpr int NST = (128 + 64) * BK * 2;       // 24 KiB per stage
+        static bool n_attr = false;
+        if (!n_attr) {
+            (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NST);
+            (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NST);
+            n_attr = true;
+        }
+        if (single) {
+            if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2, 2>), g, dim3(256), NST, st, L);
+            else      hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2, 2>), g, dim3(256), NST, st, L);
+        } else {
+            if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 2, 2, 2>), g, dim3(256), 2 * NST, st, L);
+            else      hipLaunchKernelGGL((conv_gather_kernel<false, 2, 2, 2>), g, dim3(256), 2 * NST, st, L);
+        }
+    } else if (row3) {
         if (row3_big) hipLaunchKernelGGL((conv_gather_row3_kernel<4>), g, dim3(512), ROW3_LDS4, st, L);
         else          hipLaunchKernelGGL((conv_gather_row3_kernel<2>), g, dim3(256), ROW3_LDS2, st, L);
     } else if (single) {
