@@ -719,12 +719,18 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         big_tiles += cdiv((long long)in.prob[i].N * in.prob[i].P * in.prob[i].Q, 256);
         grid128 += cdiv((long long)in.prob[i].N * in.prob[i].P * in.prob[i].Q, 128) * cdiv(in.K, BN);
     }
-    // 128x64 tiles (four wave rows) for layers with at most 64 output channels: no empty wave column
+    // 128x64 tiles (four wave rows of 32x64 accumulators, ~95 VGPRs: up to five blocks per CU).  Measured per
+    // launch on R50 512^2 bs16: faster than the 128x128 tile everywhere (more bytes in flight for the HBM-bound
+    // 1x1 convs: 66 vs 90 us on 64->256 @128^2; no empty wave column when K <= 64) except the long MFMA-bound
+    // reductions with many tiles (3x3, C >= 128: head towers 102 vs 121 us), which keep the wide tile.
     static const int narrow_mode = [] {
         const char* e = getenv("MI355_NARROW");
-        return e ? atoi(e) : 1;                        // 0 off, 1 K <= 64, 2 every launch (experiments)
+        return e ? atoi(e) : 3;                        // 0 off, 1 K <= 64 only, 2 every launch, 3 auto
     }();
-    const bool narrow = ksplit <= 1 && ((narrow_mode == 1 && in.K <= 64) || narrow_mode == 2);
+    const int taps0 = in.prob[0].TR * in.prob[0].TS;
+    const bool wide_wins = taps0 >= 9 && C >= 128 && grid128 >= 1024;
+    const bool narrow = ksplit <= 1 && ((narrow_mode == 1 && in.K <= 64) || narrow_mode == 2 ||
+                                        (narrow_mode == 3 && (in.K <= 64 || !wide_wins)));
     if (narrow) grid128 = grid128 / cdiv(in.K, BN) * cdiv(in.K, 64);
     // One stage (33 KiB of LDS, 3 blocks = 12 waves per CU) also wins for LONG reductions once the launch has
     // at least three 128x128 tiles per CU: measured on the head tower convs 1010 TFLOP/s against 920 for the
