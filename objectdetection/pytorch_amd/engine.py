@@ -193,6 +193,10 @@ class RetinaPlan(object):
         self.cls_tower = [add('classificationModel.conv%d' % i, getattr(m.classificationModel, 'conv%d' % i))
                           for i in range(1, 5)]
         self.cls_out = add('classificationModel.output', m.classificationModel.output)
+        # gradient-side channel pitch of the head outputs: a multiple of 64 (720 -> 768, 36 -> 64), so that their
+        # data gradient (C = pitch) runs on the non-flat kernels; pad channels of d loss / d logit stay zero
+        for s in (self.reg_out, self.cls_out):
+            s.Kpad = -(-s.K // 64) * 64
 
     def _alloc_params(self):
         """bf16 shadow arena, folded-BN arena, raw-wgrad scratch arena, and the flat parameter-
