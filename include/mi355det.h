@@ -28,6 +28,8 @@ extern "C" {
 #define MI355_ENOSPC (-3)   /* workspace too small */
 
 int mi355_version(void);
+/* Order `side_stream` behind everything issued to `main_stream` so far (event record + stream wait). */
+int mi355_stream_fork(void* main_stream, void* side_stream);
 const char* mi355_last_error(void);
 
 /* ---- anchors : architectures/anchors.py:38-60 (Anchors.forward), :62-97, :99-119 -------- */

@@ -171,8 +171,10 @@ class RetinaNet(nn.Module):
         if not img.is_cuda:
             raise RuntimeError('mi355det RetinaNet: input on %s; the HIP path needs a ROCm GPU tensor '
                                '(there is no CPU fallback)' % img.device)
-        for m in self.modules():
-            if isinstance(m, nn.BatchNorm2d) and m.training:
+        if getattr(self, '_bn_list', None) is None:          # (module objects are stable; `.training` is read live)
+            self._bn_list = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        for m in self._bn_list:
+            if m.training:
                 raise RuntimeError('train-mode BatchNorm is not on the frozen-BN hot path: call '
                                    'freeze_bn() as train.py:273-277 does')
         w = self.conv1.weight

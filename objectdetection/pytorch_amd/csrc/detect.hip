@@ -19,6 +19,25 @@ thread_local char g_err[512] = {0};
 using namespace mi355;
 
 extern "C" int mi355_version(void) { return 1; }
+
+// Fork: everything issued to `main_stream` so far happens-before whatever is issued to `side_stream`
+// next (hipEventRecord + hipStreamWaitEvent on a small pool of timing-free events; one host call instead
+// of three Python-level ones per weight-gradient launch of the two-stream schedule).
+extern "C" int mi355_stream_fork(void* main_stream, void* side_stream) {
+    constexpr int POOL = 64;
+    static thread_local hipEvent_t ev[POOL];
+    static thread_local int next = -1;
+    if (next < 0) {
+        for (int i = 0; i < POOL; ++i)
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return mi355::fail(MI355_ELAUNCH, "stream_fork: event pool");
+        next = 0;
+    }
+    hipEvent_t e = ev[next];
+    next = (next + 1) % POOL;
+    if (hipEventRecord(e, (hipStream_t)main_stream) != hipSuccess) return mi355::fail(MI355_ELAUNCH, "stream_fork: record");
+    if (hipStreamWaitEvent((hipStream_t)side_stream, e, 0) != hipSuccess) return mi355::fail(MI355_ELAUNCH, "stream_fork: wait");
+    return MI355_OK;
+}
 extern "C" const char* mi355_last_error(void) { return g_err; }
 
 // ============================================================================ anchors

@@ -107,9 +107,11 @@ class RetinaPlan(object):
         return t
 
     def _ptr_signature(self):
-        sig = [p.data_ptr() for p in self.model.parameters()]
-        sig += [b.data_ptr() for b in self.model.buffers()]
-        return sig
+        # (cached tensor objects: walking the module tree costs ~1 ms per step; `.data` re-homing, `.to()` and
+        # load_state_dict all keep the Parameter / buffer objects and change or keep their storage)
+        if getattr(self, '_sig_tensors', None) is None:
+            self._sig_tensors = list(self.model.parameters()) + list(self.model.buffers())
+        return [t.data_ptr() for t in self._sig_tensors]
 
     def stale(self):
         return self._param_ptrs != self._ptr_signature()
@@ -131,13 +133,11 @@ class RetinaPlan(object):
         # (not while a hipGraph is being captured: a branched graph replayed slower than the single-stream one
         # and one replay disagreed with the eager schedule; graphs keep the single-stream order)
         side = self._side_stream() if (self.use_side and not torch.cuda.is_current_stream_capturing()) else None
+        fork = self.lib.mi355_stream_fork
         for fn, args, name in steps:
             if side is not None and (name in self.SIDE_STEPS or id(args) in self._side_ids):
-                main = torch.cuda.current_stream(self.dev)
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-                rc = fn(*args, c_vp(side.cuda_stream))
+                ss = c_vp(side.cuda_stream)
+                rc = fork(s, ss) or fn(*args, ss)            # side stream ordered behind main's launches so far
                 self._side_dirty = True
             else:
                 rc = fn(*args, s)
@@ -783,7 +783,7 @@ class RetinaPlan(object):
             return self._side
         return torch.cuda.current_stream(self.dev)
 
-    def run_backward(self, g_cls, g_reg):
+    def run_backward(self, g_cls, g_reg, want_views=True):
         arena = self.begin_backward(g_cls, g_reg)
         st = self._stream()
         if type(self)._build_backward is RetinaPlan._build_backward and self.pgrad_specs:
@@ -795,6 +795,8 @@ class RetinaPlan(object):
             self.join_side()
             self._run_param_grads(arena, st)
         self._extra_param_grads(arena, st)
+        if not want_views:
+            return None
         return [self.grad_view(p, arena) if p.requires_grad else None for p in self.params]
 
     def _zero_extra(self):

@@ -122,7 +122,7 @@ class Trainer(object):
         plan.run_heads(img)
         losses = plan.run_loss(anchors, annot)
         # loss = cls.mean() + reg.mean() (train.py:312-314): upstream gradient 1 for both
-        plan.run_backward(self.ones[0:1], self.ones[1:2])
+        plan.run_backward(self.ones[0:1], self.ones[1:2], want_views=False)
         return plan, losses
 
     def _exchange(self, plan, losses):
