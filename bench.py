@@ -51,6 +51,9 @@ def parse():
     ap.add_argument('--graph', type=int, default=int(os.environ.get('MI355_GRAPH', '0')),
                     help='replay the step from captured hipGraphs (default off: the step is GPU-bound and the '
                          'two-stream schedule runs faster launched eagerly than as a branched graph)')
+    ap.add_argument('--infer', action='store_true',
+                    help='measure inference instead (SURVEY 8d): heads at --batch, and the B=1 decode + NMS path; '
+                         'prints its own JSON line (not the headline metric)')
     ap.add_argument('--torch-optim', action='store_true',
                     help='autograd + torch clip/AdamW instead of the flat HIP optimizer')
     return ap.parse_args()
@@ -191,6 +194,36 @@ def cpu_baseline(depth, size, sd, num_classes):
                       'torch CPU oracle' % (n, B, depth, size, size)}
 
 
+def infer_bench(args, model, name, img, dev):
+    """Inference side of SURVEY 8d: (a) batched heads (`return_head=True`), (b) the reference's B=1 decode
+    tail (scores > 0.05, class-agnostic NMS 0.5: retinanet.py:297-318) including the host-visible outputs."""
+    model.eval()
+    retina = args.arch == 'retinanet'
+
+    def timed(fn, n):
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    with torch.no_grad():
+        one = img[:1].contiguous()
+        t_dec = timed(lambda: model(one, return_loss=False), args.steps)
+        out = {'metric': 'images/sec inference (%s, %dx%d)' % (name, args.size, args.size), 'unit': 'images/sec',
+               'n_gpus': 1, 'higher_is_better': True, 'dtype': 'bf16', 'data': 'synthetic',
+               'b1_decode_nms': {'value': round(1.0 / t_dec, 2), 'ms_per_image': round(1e3 * t_dec, 3)}}
+        if retina:
+            t_heads = timed(lambda: model(img, return_head=True), args.steps)
+            out['heads_batched'] = {'batch': args.batch, 'value': round(args.batch / t_heads, 2),
+                                    'ms_per_batch': round(1e3 * t_heads, 3)}
+        out['value'] = out.get('heads_batched', out['b1_decode_nms'])['value']
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -216,6 +249,8 @@ def main():
     # each rank owns its shard of the global batch (weak scaling: per-GPU batch fixed)
     img = torch.from_numpy(synth.synth_images(B, S, S, seed=100 + rank)).to(dev)
     ann = torch.from_numpy(synth.synth_annotations(B, S, S, 8, 16, num_classes, seed=200 + rank)).to(dev)
+    if args.infer:
+        return infer_bench(args, model, name, img, dev)
     loss_acc = torch.zeros(2, device=dev)
     if args.torch_optim:
         params = [p for p in model.parameters()]
