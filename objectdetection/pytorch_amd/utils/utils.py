@@ -65,3 +65,22 @@ def init_weights(model):
             module.weight.data.copy_(w)               # copy_ keeps the parameter's (channels-last) strides
             if module.bias is not None:
                 module.bias.data.zero_()
+
+
+def replace_w_sync_bn(m):
+    """utils/utils.py:140-168: swap every nn.BatchNorm2d attribute (recursively) for SynchronizedBatchNorm2d,
+    keeping its parameters and running statistics."""
+    from .sync_batchnorm import SynchronizedBatchNorm2d
+    for var_name in dir(m):
+        target_attr = getattr(m, var_name)
+        if type(target_attr) == torch.nn.BatchNorm2d:
+            new = SynchronizedBatchNorm2d(target_attr.num_features, target_attr.eps, target_attr.momentum,
+                                          target_attr.affine)
+            new.running_mean = target_attr.running_mean
+            new.running_var = target_attr.running_var
+            if target_attr.affine:
+                new.weight = target_attr.weight
+                new.bias = target_attr.bias
+            setattr(m, var_name, new.to(target_attr.running_mean.device))
+    for var_name, children in m.named_children():
+        replace_w_sync_bn(children)
