@@ -452,13 +452,15 @@ __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(
 // 8 (WM = 2), and a third of the gather-address arithmetic: the generic kernel is bound by exactly
 // those (vector-memory issue, not MFMA).  Staged row j of a group holds the input pixel below
 // "virtual output pixel" m0 - 1 + j; output row i and column tap s read staged row i + s.
-template <int WM>
-__global__ __launch_bounds__(WM * 128, 2) void conv_gather_row3_kernel(const LaunchDev L) {
+// STAGES = 1: one activation buffer + one weight buffer (33 KiB): three blocks per CU, the DMA latency is
+// hidden by the resident waves instead of a second stage (as in the generic one-stage kernel).
+template <int WM, int STAGES = 2>
+__global__ __launch_bounds__(WM * 128, STAGES == 1 ? 3 : 2) void conv_gather_row3_kernel(const LaunchDev L) {
     constexpr int NTHREADS = WM * 128, BM = WM * 64;
     constexpr int AROWS = BM + 8;                      // staged rows (BM + 2 used), 8-row DMA granules
     constexpr int A_BYTES = AROWS * BK * 2;
     constexpr int Z_ROW = (AROWS - 1) * 128;           // staged rows >= BM + 2 are never in range: zeros
-    constexpr int B_OFF = 2 * A_BYTES;
+    constexpr int B_OFF = STAGES * A_BYTES;
     constexpr int B_BYTES = BN * BK * 2;
     constexpr int NB = 1024 / NTHREADS;
     constexpr int ROWSTEP = NTHREADS / 8;
@@ -584,8 +586,10 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_row3_kernel(const Lau
     const int b_rd = (wn * 64 + fr) * 128;
     const int b_sw0 = (fq ^ (fr & 7)) << 4, b_sw1 = ((4 + fq) ^ (fr & 7)) << 4;
 
-    issue_a(0);
-    issue_b(0);
+    if (STAGES == 2) {
+        issue_a(0);
+        issue_b(0);
+    }
     init_acc(acc, L, n0, wn, fq);
 
     int abuf = 0, step = 0;
@@ -593,10 +597,16 @@ __global__ __launch_bounds__(WM * 128, 2) void conv_gather_row3_kernel(const Lau
 #pragma unroll
         for (int sft = 0; sft < 3; ++sft) {            // static: fragment addresses stay in registers
             __syncthreads();                           // every DMA issued so far has landed (vmcnt(0))
-            if (sft == 0 && group + 1 < ngroups) issue_a(abuf ^ 1);   // last read two groups ago
-            if (step + 1 < nsteps) issue_b((step + 1) & 1);
-            const unsigned char* sa = smem + abuf * A_BYTES;
-            const unsigned char* sb = smem + B_OFF + (step & 1) * B_BYTES;
+            if (STAGES == 2) {
+                if (sft == 0 && group + 1 < ngroups) issue_a(abuf ^ 1);   // last read two groups ago
+                if (step + 1 < nsteps) issue_b((step + 1) & 1);
+            } else {                                   // (the barrier above: every read of the buffers retired)
+                if (sft == 0) issue_a(0);
+                issue_b(0);
+                __syncthreads();
+            }
+            const unsigned char* sa = smem + (STAGES == 2 ? abuf : 0) * A_BYTES;
+            const unsigned char* sb = smem + B_OFF + (STAGES == 2 ? (step & 1) * B_BYTES : 0);
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 s8v af[4], bf[4];
@@ -748,7 +758,8 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         return e ? atoi(e) : 2;
     }();
     const bool splitk = ksplit > 1;
-    bool row3 = !flat && row3_mode > 0 && !splitk && !many && !narrow;   // 3x3 / stride 1 / same: column taps share a staging
+    static const int row3_single = [] { const char* e = getenv("MI355_ROW3_SINGLE"); return e ? atoi(e) : 1; }();
+    bool row3 = !flat && row3_mode > 0 && !splitk && (!many || row3_single) && !narrow;   // 3x3 / stride 1 / same: column taps share a staging
     for (int i = 0; i < in.nprob && row3; ++i) {
         const Mi355ConvProblem& s = in.prob[i];
         // (data gradients walk the taps downwards: dw0 = +1, dws = -1; canonicalised below)
@@ -866,8 +877,9 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
             else      hipLaunchKernelGGL((conv_gather_kernel<false, 2, 2, 2>), g, dim3(256), 2 * NST, st, L);
         }
     } else if (row3) {
-        if (row3_big) hipLaunchKernelGGL((conv_gather_row3_kernel<4>), g, dim3(512), ROW3_LDS4, st, L);
-        else          hipLaunchKernelGGL((conv_gather_row3_kernel<2>), g, dim3(256), ROW3_LDS2, st, L);
+        if (row3_big)   hipLaunchKernelGGL((conv_gather_row3_kernel<4>), g, dim3(512), ROW3_LDS4, st, L);
+        else if (many)  hipLaunchKernelGGL((conv_gather_row3_kernel<2, 1>), g, dim3(256), (128 + 8) * BK * 2 + BN * BK * 2, st, L);
+        else            hipLaunchKernelGGL((conv_gather_row3_kernel<2>), g, dim3(256), ROW3_LDS2, st, L);
     } else if (single) {
         if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
         else      hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
