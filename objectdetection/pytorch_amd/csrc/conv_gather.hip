@@ -232,15 +232,14 @@ __device__ __forceinline__ void gather_epilogue(f4v (&acc)[TA][4], const LaunchD
     }
 }
 
-// WM = wave rows (each wave owns 64 x 64 outputs; 2 wave columns): tile = (WM*64) x 128, WM*128 threads.
-// <WM 2, STAGES 2>: 128x128, double-buffered k-loop, 64 KiB LDS, 2 blocks/CU.
-// <WM 2, STAGES 1>: one stage, 33 KiB LDS, 3-4 blocks/CU: short reductions (<= 2 k-steps) are HBM /
-//                   issue bound and live on resident blocks, not on intra-block overlap.
-// <WM 4, STAGES 3>: 256x128, 8 waves, 1 block/CU, THREE stages with a counted `s_waitcnt vmcnt` and a
-//                   raw s_barrier: the LDS-DMA of k-steps t+1 and t+2 stays in flight across the barrier
-//                   of k-step t (cdna_hip_programming.md §5 "Pipelining across barriers").
+// WM = wave rows of 64 output pixels (WM 2: 128-row tile, 4 waves).  Variants, chosen per launch on the host:
+// <STAGES 2, TA 4>: 128x128, double-buffered k-loop, 64 KiB LDS, 2 blocks/CU (split-K launches).
+// <STAGES 1, TA 4>: 128x128, one stage, 33 KiB LDS, 3 blocks/CU: resident waves instead of a second stage hide
+//                   the LDS-DMA latency (long many-tile reductions that the row-of-taps kernel cannot take).
 // <.., TA 2>:       128x64 tile, four wave rows of 32x64 accumulators (half the registers: up to 5 blocks per
-//                   CU): layers with K <= 64 (stem, layer1, box output) without an empty wave column.
+//                   CU): everything else - HBM-bound 1x1 convs, layers with K <= 64, small launches.
+// (Measured and dropped this round: a 256x128 tile with a 3-stage counted-vmcnt ring at one block per CU and
+//  a 4-stage 128x128 ring - both slower than more resident blocks.)
 template <bool FLAT, int STAGES, int WM, int TA = 4>
 __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(const LaunchDev L) {
     static_assert(TA == 4 || WM == 2, "narrow tile: 4 waves");
@@ -399,27 +398,7 @@ __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(
     if (ksteps > 0) issue(0, 0);
     // (bias loads are issued behind the first stage's DMA so that both latencies overlap)
     init_acc<TA>(acc, L, n0, wn, fq);
-    if (STAGES >= 3) {
-        // ring of STAGES buffers: stage ks is read while the next STAGES - 2 are in flight.  Per thread a
-        // stage is 4 + NB DMA instructions, so `vmcnt(r * (4 + NB))` retires stage ks and leaves the r
-        // younger stages flying (a raw s_barrier: __syncthreads would drain vmcnt to 0).
-        constexpr int D = STAGES - 1, G = 4 + NB;
-#pragma unroll
-        for (int i = 1; i < D; ++i)
-            if (i < ksteps) issue(i, i);
-        for (int ks = 0; ks < ksteps; ++ks) {
-            // (lgkmcnt(0): this wave's ds_reads of the buffer refilled below have landed)
-            const int r = min(D - 1, ksteps - 1 - ks);
-            if (r >= 2 && D > 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * G) : "memory");
-            else if (r == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (ks + D < ksteps) issue(ks + D, (ks + D) % STAGES);
-            compute(ks % STAGES);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    } else if (STAGES == 2) {
+    if (STAGES == 2) {
         __syncthreads();
         for (int ks = 0; ks < ksteps; ++ks) {
             const int buf = ks & 1;
@@ -718,63 +697,49 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     const int C = in.prob[0].C;
     MI355_REQUIRE(C > 0 && C % 8 == 0, "conv_gather: C must be a multiple of 8");
     const bool flat = C % BK != 0;
-    // k-steps of the longest problem decide the pipeline depth; the 256-row / 3-stage variant runs one
-    // block per CU, so it needs a long reduction and enough tiles to cover the chip.
     int max_ksteps = 0;
-    long long big_tiles = 0, grid128 = 0;
+    long long grid128 = 0;                             // 128x128 tiles of the launch
     for (int i = 0; i < in.nprob; ++i) {
         const int taps = in.prob[i].TR * in.prob[i].TS;
         const int ks = flat ? (taps * (C / 8) + 7) / 8 : taps * (C / BK);
         if (ks > max_ksteps) max_ksteps = ks;
-        big_tiles += cdiv((long long)in.prob[i].N * in.prob[i].P * in.prob[i].Q, 256);
         grid128 += cdiv((long long)in.prob[i].N * in.prob[i].P * in.prob[i].Q, 128) * cdiv(in.K, BN);
     }
-    // 128x64 tiles (four wave rows of 32x64 accumulators, ~95 VGPRs: up to five blocks per CU).  Measured per
-    // launch on R50 512^2 bs16: faster than the 128x128 tile everywhere (more bytes in flight for the HBM-bound
-    // 1x1 convs: 66 vs 90 us on 64->256 @128^2; no empty wave column when K <= 64) except the long MFMA-bound
-    // reductions with many tiles (3x3, C >= 128: head towers 102 vs 121 us), which keep the wide tile.
+    const bool splitk = ksplit > 1;
+    // ---- kernel choice (per-launch A/B on R50 512^2 bs16 with tools/profile_plan.py; env knobs keep the
+    //      alternatives reachable).
+    // 128x64 tiles (four wave rows of 32x64 accumulators, ~95 VGPRs: up to five blocks per CU): faster than the
+    // 128x128 tile everywhere (more bytes in flight for the HBM-bound 1x1 convs: 66 vs 90 us on 64->256 @128^2;
+    // no empty wave column when K <= 64: stem 111 vs 209 us) except the long MFMA-bound reductions with many
+    // tiles (3x3, C >= 128: head towers 102 vs 121 us), which keep the wide tile.
     static const int narrow_mode = [] {
         const char* e = getenv("MI355_NARROW");
         return e ? atoi(e) : 3;                        // 0 off, 1 K <= 64 only, 2 every launch, 3 auto
     }();
     const int taps0 = in.prob[0].TR * in.prob[0].TS;
     const bool wide_wins = taps0 >= 9 && C >= 128 && grid128 >= 1024;
-    const bool narrow = ksplit <= 1 && ((narrow_mode == 1 && in.K <= 64) || narrow_mode == 2 ||
-                                        (narrow_mode == 3 && (in.K <= 64 || !wide_wins)));
+    const bool narrow = !splitk && ((narrow_mode == 1 && in.K <= 64) || narrow_mode == 2 ||
+                                    (narrow_mode == 3 && (in.K <= 64 || !wide_wins)));
     if (narrow) grid128 = grid128 / cdiv(in.K, BN) * cdiv(in.K, 64);
-    // One stage (33 KiB of LDS, 3 blocks = 12 waves per CU) also wins for LONG reductions once the launch has
-    // at least three 128x128 tiles per CU: measured on the head tower convs 1010 TFLOP/s against 920 for the
-    // double-buffered form (2 blocks per CU) and 980 for the row-of-taps kernel; resident waves, not the
-    // depth of one block's pipeline, hide the LDS-DMA latency.
+    // One stage (33 KiB of LDS, 3 blocks = 12 waves per CU) for <= 2 k-steps and for LONG reductions once the
+    // launch has at least three tiles per CU: on the head tower convs 1010 TFLOP/s against 920 double-buffered
+    // (2 blocks per CU); resident waves, not the depth of one block's pipeline, hide the LDS-DMA latency.
     static const int single_min_grid = [] { const char* e = getenv("MI355_SINGLE_MIN_GRID"); return e ? atoi(e) : 768; }();
-    const bool many = single_min_grid > 0 && grid128 >= single_min_grid && ksplit <= 1;
-    const bool single = (max_ksteps <= 2 || many) && ksplit <= 1;
-    static const int big_min_grid = [] {
-        const char* e = getenv("MI355_GATHER_BIG");
-        return e ? atoi(e) : 256;
-    }();
+    const bool many = single_min_grid > 0 && grid128 >= single_min_grid && !splitk;
+    const bool single = (max_ksteps <= 2 || many) && !splitk;
+    // Row-of-taps kernel for the wide 3x3 / stride-1 / same launches (MI355_ROW3=0 disables it).
     static const int row3_mode = [] {
         const char* e = getenv("MI355_ROW3");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 1;
     }();
-    const bool splitk = ksplit > 1;
-    static const int row3_single = [] { const char* e = getenv("MI355_ROW3_SINGLE"); return e ? atoi(e) : 1; }();
-    bool row3 = !flat && row3_mode > 0 && !splitk && (!many || row3_single) && !narrow;   // 3x3 / stride 1 / same: column taps share a staging
+    bool row3 = !flat && row3_mode > 0 && !splitk && !narrow;
     for (int i = 0; i < in.nprob && row3; ++i) {
         const Mi355ConvProblem& s = in.prob[i];
         // (data gradients walk the taps downwards: dw0 = +1, dws = -1; canonicalised below)
         row3 = s.TR == 3 && s.TS == 3 && s.sh == 1 && s.sw == 1 && (s.dhs == 1 || s.dhs == -1) &&
                ((s.dws == 1 && s.dw0 == -1) || (s.dws == -1 && s.dw0 == 1)) && s.Q == s.W;
     }
-    static const int deep_over_row3 = [] {
-        const char* e = getenv("MI355_DEEP_OVER_ROW3");
-        return e ? atoi(e) : 288;
-    }();
-    if (deep_over_row3 && grid128 <= deep_over_row3) row3 = false;
-    const bool row3_big = row3 && row3_mode == 4;
-    const bool big = !row3 && !splitk && !single && !narrow && !flat && max_ksteps >= 6 && big_min_grid > 0 &&
-                     big_tiles * cdiv(in.K, BN) >= big_min_grid;
-    const int BM = (big || row3_big) ? 256 : 128;
+    constexpr int BM = 128;
     for (int i = 0; i < in.nprob; ++i) {
         const Mi355ConvProblem& s = in.prob[i];
         MI355_REQUIRE(s.in && s.out, "conv_gather: problem %d null in/out", i);
@@ -840,56 +805,37 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         grid *= ksplit;
         MI355_REQUIRE(grid < 0x7fffffffLL, "conv_gather_splitk: grid");
     }
-    constexpr int STAGE2 = (128 + BN) * BK * 2, STAGE3 = (256 + BN) * BK * 2;
-    constexpr int ROW3_LDS2 = 2 * (128 + 8) * BK * 2 + 2 * BN * BK * 2, ROW3_LDS4 = 2 * (256 + 8) * BK * 2 + 2 * BN * BK * 2;
+    constexpr int STAGE2 = (128 + BN) * BK * 2;        // 32 KiB
+    constexpr int NST = (128 + 64) * BK * 2;           // 24 KiB: narrow tile
+    constexpr int ROW3_A = (128 + 8) * BK * 2, ROW3_B = BN * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);
         (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);
-        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
-        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
-        (void)hipFuncSetAttribute((const void*)conv_gather_row3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ROW3_LDS2);
-        (void)hipFuncSetAttribute((const void*)conv_gather_row3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ROW3_LDS4);
+        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NST);
+        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NST);
+        (void)hipFuncSetAttribute((const void*)conv_gather_row3_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ROW3_A + 2 * ROW3_B);
         attr_set = true;
     }
-    // at most one 128x128 block per CU anyway: a 4-stage ring (128 KiB) hides the DMA latency that the
-    // two-stage loop exposes when no second block shares the CU
-    static const int deep_max_grid = [] {
-        const char* e = getenv("MI355_GATHER_DEEP");
-        return e ? atoi(e) : 288;
-    }();
-    const bool deep = !flat && !big && !row3 && !narrow && max_ksteps >= 6 && grid <= deep_max_grid;
-    const dim3 g((unsigned)grid);
+    const dim3 g((unsigned)grid), b256(256);
     hipStream_t st = (hipStream_t)stream;
     if (narrow) {
-        constexpr int NST = (128 + 64) * BK * 2;       // 24 KiB per stage
-        static bool n_attr = false;
-        if (!n_attr) {
-            (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NST);
-            (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NST);
-            n_attr = true;
-        }
         if (single) {
-            if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2, 2>), g, dim3(256), NST, st, L);
-            else      hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2, 2>), g, dim3(256), NST, st, L);
+            if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2, 2>), g, b256, NST, st, L);
+            else      hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2, 2>), g, b256, NST, st, L);
         } else {
-            if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 2, 2, 2>), g, dim3(256), 2 * NST, st, L);
-            else      hipLaunchKernelGGL((conv_gather_kernel<false, 2, 2, 2>), g, dim3(256), 2 * NST, st, L);
+            if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 2, 2, 2>), g, b256, 2 * NST, st, L);
+            else      hipLaunchKernelGGL((conv_gather_kernel<false, 2, 2, 2>), g, b256, 2 * NST, st, L);
         }
     } else if (row3) {
-        if (row3_big)   hipLaunchKernelGGL((conv_gather_row3_kernel<4>), g, dim3(512), ROW3_LDS4, st, L);
-        else if (many)  hipLaunchKernelGGL((conv_gather_row3_kernel<2, 1>), g, dim3(256), (128 + 8) * BK * 2 + BN * BK * 2, st, L);
-        else            hipLaunchKernelGGL((conv_gather_row3_kernel<2>), g, dim3(256), ROW3_LDS2, st, L);
+        if (many) hipLaunchKernelGGL((conv_gather_row3_kernel<2, 1>), g, b256, ROW3_A + ROW3_B, st, L);
+        else      hipLaunchKernelGGL((conv_gather_row3_kernel<2, 2>), g, b256, 2 * ROW3_A + 2 * ROW3_B, st, L);
     } else if (single) {
-        if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
-        else      hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2>), g, dim3(256), EPI_BYTES, st, L);
-    } else if (big) {
-        hipLaunchKernelGGL((conv_gather_kernel<false, 3, 4>), g, dim3(512), 3 * STAGE3, st, L);
-    } else if (deep) {
-        hipLaunchKernelGGL((conv_gather_kernel<false, 4, 2>), g, dim3(256), 4 * STAGE2, st, L);
+        if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2>), g, b256, EPI_BYTES, st, L);
+        else      hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2>), g, b256, EPI_BYTES, st, L);
     } else {
-        if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 2, 2>), g, dim3(256), 2 * STAGE2, st, L);
-        else      hipLaunchKernelGGL((conv_gather_kernel<false, 2, 2>), g, dim3(256), 2 * STAGE2, st, L);
+        if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 2, 2>), g, b256, 2 * STAGE2, st, L);
+        else      hipLaunchKernelGGL((conv_gather_kernel<false, 2, 2>), g, b256, 2 * STAGE2, st, L);
     }
     if (splitk) {
         long long off = 0;
