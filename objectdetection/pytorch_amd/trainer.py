@@ -90,6 +90,10 @@ class Trainer(object):
     def _begin(self, img, annot):
         model = self.model
         plan = model._plan(img)
+        # one compute stream beside the collectives: the two-stream schedule and collectives issued between its
+        # launches serialised pathologically in the two-rank rehearsal (gloo on one GPU: 1.2 s per step against
+        # 45 ms single-stream), and an RCCL node was not available to show otherwise
+        plan.use_side = False
         anchors = model.anchors(img)
         plan.run_heads(img)
         losses = plan.run_loss(anchors, annot)
@@ -109,7 +113,7 @@ class Trainer(object):
         works = []
         for seg in plan.backward_segments(self.segment_bytes):
             plan.run_backward_segment(seg)
-            with torch.cuda.stream(plan.exchange_stream()):        # the collective waits for THAT stream
+            with torch.cuda.stream(plan.exchange_stream()):        # (= the current stream: one compute stream)
                 works.append((self._allreduce_async(grad[seg[1]:seg[2]]), seg))
         plan.join_side()
         self._finish_exchange(plan, works)
