@@ -60,6 +60,8 @@ def parse():
 
 
 def build_model(depth, num_classes, dev, arch='retinanet'):
+    if arch != 'retinanet' and not arch.startswith('efficientdet-d'):
+        raise SystemExit("--arch must be 'retinanet' or 'efficientdet-dN', got %r" % arch)
     if arch.startswith('efficientdet'):
         from objectdetection.pytorch_amd.architectures import efficientdet
         model = efficientdet.build_efficientdet(arch, num_classes=num_classes)

@@ -79,11 +79,74 @@ __global__ void dwconv_fwd_kernel(const unsigned short* __restrict__ in, const f
     store8(out + t * 8, acc);
 }
 
+
+// Stride-1 form of the forward: a thread produces FOUR neighbouring output pixels of one 8-channel chunk, so a
+// kernel row costs 4 + K - 1 input loads for 4 K taps (K = 5: 10 loads per output instead of 25).
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_fwd_s1_kernel(const unsigned short* __restrict__ in, const float* __restrict__ w_t,
+                                                            const float* __restrict__ bias, unsigned short* __restrict__ out,
+                                                            int N, int H, int W, int C, int pad_t, int pad_l, int P, int Q) {
+    const int c8n = C >> 3, Q4 = (Q + 3) >> 2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * P * Q4 * c8n) return;
+    const int c8 = (int)(t % c8n);
+    long long r = t / c8n;
+    const int q0 = (int)(r % Q4) * 4;  r /= Q4;
+    const int p = (int)(r % P);
+    const int n = (int)(r / P);
+    float acc[4][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[o][e] = bias ? bias[c8 * 8 + e] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+        const int h = p - pad_t + a;
+        if ((unsigned)h >= (unsigned)H) continue;
+        const unsigned short* row = in + ((long long)n * H + h) * W * C + c8 * 8;
+        float xw[4 + K - 1][8];
+#pragma unroll
+        for (int j = 0; j < 4 + K - 1; ++j) {
+            const int w = q0 - pad_l + j;
+            if ((unsigned)w < (unsigned)W) load8(row + (long long)w * C, xw[j]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xw[j][e] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < K; ++b) {
+            float wt[8];
+            const float4 w0 = *reinterpret_cast<const float4*>(w_t + (a * K + b) * C + c8 * 8);
+            const float4 w1 = *reinterpret_cast<const float4*>(w_t + (a * K + b) * C + c8 * 8 + 4);
+            wt[0] = w0.x; wt[1] = w0.y; wt[2] = w0.z; wt[3] = w0.w; wt[4] = w1.x; wt[5] = w1.y; wt[6] = w1.z; wt[7] = w1.w;
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[o][e] += xw[o + b][e] * wt[e];
+        }
+    }
+    unsigned short* op = out + (((long long)n * P + p) * Q + q0) * C + c8 * 8;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (q0 + o < Q) store8(op + (long long)o * C, acc[o]);
+}
+
 extern "C" int mi355_dwconv_fwd(const void* in, int in_swish, const float* w_t, const float* bias, void* out,
                                 int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
                                 void* stream) {
     MI355_REQUIRE(in && w_t && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && k > 0 && stride > 0,
                   "dwconv_fwd: bad args");
+    if (stride == 1 && !in_swish && (k == 3 || k == 5) && P == H && Q == W) {
+        const long long tot4 = (long long)N * P * ((Q + 3) / 4) * (C / 8);
+        if (k == 3)
+            hipLaunchKernelGGL(dwconv_fwd_s1_kernel<3>, dim3(blocks_for(tot4)), dim3(256), 0, (hipStream_t)stream,
+                               (const unsigned short*)in, w_t, bias, (unsigned short*)out, N, H, W, C, pad_t, pad_l, P, Q);
+        else
+            hipLaunchKernelGGL(dwconv_fwd_s1_kernel<5>, dim3(blocks_for(tot4)), dim3(256), 0, (hipStream_t)stream,
+                               (const unsigned short*)in, w_t, bias, (unsigned short*)out, N, H, W, C, pad_t, pad_l, P, Q);
+        return check_launch("dwconv_fwd_s1_kernel");
+    }
     const long long total = (long long)N * P * Q * (C / 8);
     if (in_swish)
         hipLaunchKernelGGL(dwconv_fwd_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
@@ -239,11 +302,131 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(
     }
 }
 
+
+// Stride-1 form: a thread owns one KERNEL ROW a of one 8-channel chunk and walks whole output rows with a
+// register window of the k input pixels under the current output pixel: per pixel ONE dy load and ONE new x
+// load feed k taps (the per-tap form above re-reads both for every tap: k times the L1/L2 traffic).
+// block = 32 (kernel row, chunk) items x 8 row lanes; lanes reduced through LDS, one atomic per (tap, channel).
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_s1_kernel(
+    const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy, float* __restrict__ dw_t,
+    float* __restrict__ colsum, int N, int H, int W, int C, int pad_t, int pad_l, int P, int Q, int rows_per_block,
+    int qseg) {
+    __shared__ float s_acc[DW_PL][DW_IPB][9];
+    const int c8n = C >> 3;
+    const int il = threadIdx.x % DW_IPB, pl = threadIdx.x / DW_IPB;
+    const int item = blockIdx.x * DW_IPB + il;                 // (kernel row a, c8)
+    const int qa = blockIdx.z * qseg, qb = min(Q, qa + qseg);  // this block's column segment of every row
+    const bool live = item < K * c8n;
+    const int a = live ? item / c8n : 0, c8 = live ? item - a * c8n : 0;
+    const int nrows = N * P;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(nrows, r0 + rows_per_block);
+    float acc[K][8], cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < K; ++b)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[b][e] = 0.0f;
+    const bool do_cs = colsum != nullptr && a == 0 && live;
+    if (live) {
+        for (int r = r0 + pl; r < r1; r += DW_PL) {
+            const int n = r / P, p = r - n * P;
+            const int h = p - pad_t + a;
+            const bool row_ok = (unsigned)h < (unsigned)H;
+            if (!row_ok && !do_cs) continue;
+            const unsigned short* dyr = dy + (long long)r * Q * C + c8 * 8;
+            const unsigned short* xr = x + ((long long)n * H + (row_ok ? h : 0)) * W * C + c8 * 8;
+            float win[K][8];                              // win[b] = x(h, q + b - pad_l)
+#pragma unroll
+            for (int b = 0; b < K - 1; ++b) {
+                const int w = qa + b - pad_l;             // window of output pixel q = qa, all but the last tap
+                if (row_ok && (unsigned)w < (unsigned)W) load8(xr + (long long)w * C, win[b + 1]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) win[b + 1][e] = 0.0f;
+                }
+            }
+            for (int q = qa; q < qb; ++q) {
+#pragma unroll
+                for (int b = 0; b < K - 1; ++b)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) win[b][e] = win[b + 1][e];
+                const int w = q + K - 1 - pad_l;
+                if (row_ok && (unsigned)w < (unsigned)W) load8(xr + (long long)w * C, win[K - 1]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) win[K - 1][e] = 0.0f;
+                }
+                float g[8];
+                load8(dyr + (long long)q * C, g);
+                if (do_cs) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cs[e] += g[e];
+                }
+#pragma unroll
+                for (int b = 0; b < K; ++b)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[b][e] += win[b][e] * g[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < K; ++b) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_acc[pl][il][e] = acc[b][e];
+        __syncthreads();
+        if (pl == 0 && live) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = 0.0f;
+#pragma unroll
+                for (int l = 0; l < DW_PL; ++l) t += s_acc[l][il][e];
+                atomicAdd(dw_t + (a * K + b) * C + c8 * 8 + e, t);
+            }
+        }
+    }
+    if (colsum) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_acc[pl][il][e] = cs[e];
+        __syncthreads();
+        if (pl == 0 && do_cs) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = 0.0f;
+#pragma unroll
+                for (int l = 0; l < DW_PL; ++l) t += s_acc[l][il][e];
+                atomicAdd(colsum + c8 * 8 + e, t);
+            }
+        }
+    }
+}
+
 extern "C" int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, float* dw_t, float* colsum, int N,
                                   int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
                                   void* stream) {
     MI355_REQUIRE(x && dy && dw_t && N > 0 && C > 0 && C % 8 == 0 && k > 0, "dwconv_wgrad: bad args");
     const int nrows = N * P;
+    if (stride == 1 && !in_swish && (k == 3 || k == 5) && P == H && Q == W) {
+        const int items = k * (C / 8);
+        const int bx = (items + DW_IPB - 1) / DW_IPB;
+        const int qseg = 32, bz = (Q + qseg - 1) / qseg;      // column segments: a thread walks <= 32 pixels of a row
+        int chunks = 4096 / (bx * bz);                        // ~4096 blocks
+        if (chunks > 256) chunks = 256;
+        if (chunks < 1) chunks = 1;
+        int rows = (nrows + chunks - 1) / chunks;
+        rows = (rows + DW_PL - 1) / DW_PL * DW_PL;           // whole lane groups of rows
+        const int by = (nrows + rows - 1) / rows;
+        dim3 grid((unsigned)bx, (unsigned)by, (unsigned)bz);
+        if (k == 3)
+            hipLaunchKernelGGL(dwconv_wgrad_s1_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
+                               (const unsigned short*)dy, dw_t, colsum, N, H, W, C, pad_t, pad_l, P, Q, rows, qseg);
+        else
+            hipLaunchKernelGGL(dwconv_wgrad_s1_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
+                               (const unsigned short*)dy, dw_t, colsum, N, H, W, C, pad_t, pad_l, P, Q, rows, qseg);
+        return check_launch("dwconv_wgrad_s1_kernel");
+    }
     const int items = k * k * (C / 8);
     const int bx = (items + DW_IPB - 1) / DW_IPB;
     int chunks = 2048 / bx;                               // ~2048 blocks, <= 128-way atomic contention

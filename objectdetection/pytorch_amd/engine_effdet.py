@@ -183,19 +183,20 @@ class EffDetPlan(RetinaPlan):
         out = self.new((N, P, Q, C))
         geo = (c_int(N), c_int(H), c_int(W), c_int(C), c_int(spec.k), c_int(spec.stride), c_int(pt), c_int(pl),
                c_int(P), c_int(Q))
-        self._step(self.fwd_steps, 'mi355_dwconv_fwd', ptr(x), c_int(int(x_swish)), ptr(spec.w_t), ptr(spec.shift),
+        xs = x
+        if x_swish:
+            # swish ONCE per element (one elementwise pass, kept for the weight gradient) instead of once per
+            # tap inside the 9- / 25-tap loop of the depthwise kernel: the expf dominated that kernel
+            xs = self.new(tuple(x.shape))
+            self._step(self.fwd_steps, 'mi355_swish_bf16', ptr(x), ptr(xs), c_i64(x.numel()))
+        self._step(self.fwd_steps, 'mi355_dwconv_fwd', ptr(xs), c_int(0), ptr(spec.w_t), ptr(spec.shift),
                    ptr(out), *geo)
 
         def bwd():
             if not self.has_grad(out):
                 return
             dy = self.grad(out)
-            xw, xw_sw = x, x_swish
-            if x_swish:                                 # swish once, not once per tap
-                xw = self._swish_tmp(x.numel()).view(x.shape)
-                self._step(self.bwd_steps, 'mi355_swish_bf16', ptr(x), ptr(xw), c_i64(x.numel()))
-                xw_sw = False
-            self._step(self.bwd_steps, 'mi355_dwconv_wgrad', ptr(xw), c_int(int(xw_sw)), ptr(dy), ptr(spec.G_t),
+            self._step(self.bwd_steps, 'mi355_dwconv_wgrad', ptr(xs), c_int(0), ptr(dy), ptr(spec.G_t),
                        ptr(spec.colsum if spec.bn is not None else None), *geo)
             dx = self.grad(x)
             acc = not self.first_write(x)
