@@ -132,11 +132,128 @@ __global__ __launch_bounds__(256) void dwconv_fwd_s1_kernel(const unsigned short
         if (q0 + o < Q) store8(op + (long long)o * C, acc[o]);
 }
 
+
+// LDS-tiled stride-1 "same" depthwise conv, used for the forward (FLIP = false) and for the data gradient
+// (FLIP = true: correlation of dy with the flipped taps; epilogue x swish'(z), += dx).  A block owns an
+// 8 x 32 output tile of NC8 8-channel chunks of one image: the (8 + K - 1) x (32 + K - 1) input halo tile is
+// fetched ONCE (the direct kernels fetch every input K*K times through L1/L2), kept as [chunk][pixel] planes of
+// 16-B cells (consecutive lanes = consecutive cells: conflict-free ds_read_b128), the taps' weights sit in
+// LDS too, and the outputs go back through LDS so that a pixel's NC8 chunks are stored contiguously.
+constexpr int DT_TH = 8, DT_TW = 32;
+template <int K, bool FLIP>
+__global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* __restrict__ in, const float* __restrict__ w_t,
+                                                         const float* __restrict__ bias, unsigned short* __restrict__ out,
+                                                         const unsigned short* __restrict__ zin, int accumulate,
+                                                         int N, int H, int W, int C, int nc8, int pad_t, int pad_l) {
+    constexpr int IH = DT_TH + K - 1, IW = DT_TW + K - 1, NPX = IH * IW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    s8v* tile = reinterpret_cast<s8v*>(smem);                              // [nc8][NPX]
+    float* wl = reinterpret_cast<float*>(smem + (size_t)nc8 * NPX * 16);     // [K*K][nc8*8]
+    s8v* ot = reinterpret_cast<s8v*>(smem + (size_t)nc8 * NPX * 16 + (size_t)K * K * nc8 * 32);   // [256][nc8]
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * DT_TW, p0 = blockIdx.y * DT_TH;
+    const int groups = (C >> 3) / nc8;
+    const int n = blockIdx.z / groups, c8b = (blockIdx.z - n * groups) * nc8;
+    // ---- input halo tile
+    for (int i = tid; i < NPX * nc8; i += 256) {
+        const int px = i / nc8, ch = i - px * nc8;
+        const int iy = px / IW, ix = px - iy * IW;
+        const int h = p0 - pad_t + iy, w = q0 - pad_l + ix;
+        s8v v = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W)
+            v = *reinterpret_cast<const s8v*>(in + (((long long)n * H + h) * W + w) * C + (c8b + ch) * 8);
+        tile[ch * NPX + px] = v;
+    }
+    for (int i = tid; i < K * K * nc8 * 8; i += 256) {
+        const int t = i / (nc8 * 8), c = i - t * (nc8 * 8);
+        wl[i] = w_t[(FLIP ? K * K - 1 - t : t) * C + c8b * 8 + c];
+    }
+    __syncthreads();
+    const int ty = tid >> 5, tx = tid & 31;
+    for (int ch = 0; ch < nc8; ++ch) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[(c8b + ch) * 8 + e] : 0.0f;
+#pragma unroll
+        for (int a = 0; a < K; ++a)
+#pragma unroll
+            for (int b = 0; b < K; ++b) {
+                const s8v v = tile[ch * NPX + (ty + a) * IW + tx + b];
+                const float4 w0 = *reinterpret_cast<const float4*>(wl + (a * K + b) * nc8 * 8 + ch * 8);
+                const float4 w1 = *reinterpret_cast<const float4*>(wl + (a * K + b) * nc8 * 8 + ch * 8 + 4);
+                acc[0] += bf16_to_f32((unsigned short)v[0]) * w0.x;  acc[1] += bf16_to_f32((unsigned short)v[1]) * w0.y;
+                acc[2] += bf16_to_f32((unsigned short)v[2]) * w0.z;  acc[3] += bf16_to_f32((unsigned short)v[3]) * w0.w;
+                acc[4] += bf16_to_f32((unsigned short)v[4]) * w1.x;  acc[5] += bf16_to_f32((unsigned short)v[5]) * w1.y;
+                acc[6] += bf16_to_f32((unsigned short)v[6]) * w1.z;  acc[7] += bf16_to_f32((unsigned short)v[7]) * w1.w;
+            }
+        if (FLIP) {                                        // keep fp32 until the swish' / accumulate epilogue
+            float* of = reinterpret_cast<float*>(ot);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) of[(tid * nc8 + ch) * 8 + e] = acc[e];
+        } else {
+            s8v o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(acc[e]);
+            ot[tid * nc8 + ch] = o;
+        }
+    }
+    __syncthreads();
+    // ---- outputs: piece i = (pixel, chunk), a pixel's chunks contiguous in memory
+    for (int i = tid; i < 256 * nc8; i += 256) {
+        const int px = i / nc8, ch = i - px * nc8;
+        const int p = p0 + (px >> 5), q = q0 + (px & 31);
+        if (p >= H || q >= W) continue;
+        const long long off = (((long long)n * H + p) * W + q) * C + (c8b + ch) * 8;
+        if (FLIP) {
+            const float* of = reinterpret_cast<const float*>(ot) + (long long)i * 8;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = of[e];
+            if (zin) {
+                float z[8];
+                load8(zin + off, z);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dswishf(z[e]);
+            }
+            if (accumulate) {
+                float o[8];
+                load8(out + off, o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += o[e];
+            }
+            store8(out + off, v);
+        } else {
+            *reinterpret_cast<s8v*>(out + off) = ot[i];
+        }
+    }
+}
+
+template <int K, bool FLIP>
+static int launch_dw_tile(const void* in, const float* w_t, const float* bias, void* out, const void* zin, int accumulate,
+                          int N, int H, int W, int C, int pad_t, int pad_l, void* stream) {
+    const int c8n = C / 8;
+    const int nc8 = c8n % 4 == 0 ? 4 : (c8n % 2 == 0 ? 2 : 1);
+    constexpr int NPX = (DT_TH + K - 1) * (DT_TW + K - 1);
+    const size_t lds = (size_t)nc8 * NPX * 16 + (size_t)K * K * nc8 * 32 + (size_t)256 * nc8 * (FLIP ? 32 : 16);
+    const dim3 grid((unsigned)((W + DT_TW - 1) / DT_TW), (unsigned)((H + DT_TH - 1) / DT_TH), (unsigned)(N * (c8n / nc8)));
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)dw_tile_s1_kernel<K, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((dw_tile_s1_kernel<K, FLIP>), grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short*)in, w_t,
+                       bias, (unsigned short*)out, (const unsigned short*)zin, accumulate, N, H, W, C, nc8, pad_t, pad_l);
+    return check_launch("dw_tile_s1_kernel");
+}
+
 extern "C" int mi355_dwconv_fwd(const void* in, int in_swish, const float* w_t, const float* bias, void* out,
                                 int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
                                 void* stream) {
     MI355_REQUIRE(in && w_t && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && k > 0 && stride > 0,
                   "dwconv_fwd: bad args");
+    if (stride == 1 && !in_swish && (k == 3 || k == 5) && P == H && Q == W && W >= 16 && H >= 8)
+        return k == 3 ? launch_dw_tile<3, false>(in, w_t, bias, out, nullptr, 0, N, H, W, C, pad_t, pad_l, stream)
+                      : launch_dw_tile<5, false>(in, w_t, bias, out, nullptr, 0, N, H, W, C, pad_t, pad_l, stream);
     if (stride == 1 && !in_swish && (k == 3 || k == 5) && P == H && Q == W) {
         const long long tot4 = (long long)N * P * ((Q + 3) / 4) * (C / 8);
         if (k == 3)
@@ -208,6 +325,9 @@ extern "C" int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, co
                                   int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
                                   int accumulate, void* stream) {
     MI355_REQUIRE(dy && w_t && dx && N > 0 && C > 0 && C % 8 == 0 && k > 0 && stride > 0, "dwconv_dgrad: bad args");
+    if (stride == 1 && (k == 3 || k == 5) && P == H && Q == W && W >= 16 && H >= 8 && pad_t == (k - 1) / 2 && pad_l == (k - 1) / 2)
+        return k == 3 ? launch_dw_tile<3, true>(dy, w_t, nullptr, dx, zin, accumulate, N, H, W, C, k - 1 - pad_t, k - 1 - pad_l, stream)
+                      : launch_dw_tile<5, true>(dy, w_t, nullptr, dx, zin, accumulate, N, H, W, C, k - 1 - pad_t, k - 1 - pad_l, stream);
     const long long total = (long long)N * H * W * (C / 8);
     hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)dy, w_t, (unsigned short*)dx, (const unsigned short*)zin, N, H, W, C,

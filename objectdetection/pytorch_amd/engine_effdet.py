@@ -371,7 +371,11 @@ class EffDetPlan(RetinaPlan):
         self.reg_pitch = (4 * self.A_cell + 7) // 8 * 8
         self.gcls = self.new((B, self.ncells, self.cls_pitch), zero=True)
         self.greg = self.new((B, self.ncells, self.reg_pitch), zero=True)
+        # the two heads only share the pyramid: the box head's forward launches go to the side stream (every
+        # buffer they write is their own) and run beside the class head; run_heads joins before the loss
+        self._mark_side = True
         self._head_fwd(self.reg_head, self.reg, 4 * self.A_cell, ACT_NONE, self.greg, self.reg_pitch)
+        self._mark_side = False
         self._head_fwd(self.cls_head, self.cls, C * self.A_cell, ACT_SIGMOID, self.gcls, self.cls_pitch)
         # loss state (same fused kernels as RetinaNet)
         self.losses = self.new((2,), torch.float32)
@@ -458,11 +462,24 @@ class EffDetPlan(RetinaPlan):
             return
         super(EffDetPlan, self)._step(lst, name, *args)
 
+    SIDE_STEPS = RetinaPlan.SIDE_STEPS + ('mi355_dwconv_wgrad',)
+
     def _run(self, steps, stream):
+        """As RetinaPlan._run (weight gradients on the side stream: they only read activations / output
+        gradients that are final by then and write their own G buffers), plus the python-side pseudo steps."""
         s = c_vp(stream)
         lib = self.lib
         arena = self.last_arena
+        side = self._side_stream() if (self.use_side and not torch.cuda.is_current_stream_capturing()) else None
+        fork = lib.mi355_stream_fork
         for fn, args, name in steps:
+            if side is not None and fn is not None and (name in self.SIDE_STEPS or id(args) in self._side_ids):
+                ss = c_vp(side.cuda_stream)
+                rc = fork(s, ss) or fn(*args, ss)
+                self._side_dirty = True
+                if rc:
+                    raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, lib.mi355_last_error().decode()))
+                continue
             if fn is None:
                 if name == '__se_fc_bwd__':
                     spec, pool, rpre, gate, ggate, gpool, N, slabs = self._se_bwd[args[0]]
