@@ -725,6 +725,7 @@ class RetinaPlan(object):
         if rc:
             raise _lib.Mi355Error('nchw_to_nhwc: %s' % self.lib.mi355_last_error().decode())
         self._run(self.prep_steps, st)
+        self.join_side()                               # (EfficientDet: half of the depthwise weight prep ran there)
         self._run(self.fwd_steps, st)
         self.join_side()
 

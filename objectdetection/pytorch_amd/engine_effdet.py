@@ -129,7 +129,8 @@ class EffDetPlan(RetinaPlan):
     # ------------------------------------------------------------------ prep
     def _build_prep(self):
         super(EffDetPlan, self)._build_prep()
-        for s in self.dw_specs:
+        for i, s in enumerate(self.dw_specs):
+            self._mark_side = bool(i & 1)             # independent tiny launches: every other layer on the side stream
             if s.bn is not None:
                 bn = s.bn
                 self._step(self.prep_steps, 'mi355_bn_fold', ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
@@ -137,6 +138,7 @@ class EffDetPlan(RetinaPlan):
             assert s.conv.weight.is_contiguous()
             self._step(self.prep_steps, 'mi355_dw_prep_weight', ptr(s.conv.weight), ptr(s.scale), c_int(s.C),
                        c_int(s.k), ptr(s.w_t))
+        self._mark_side = False
 
     # ------------------------------------------------------------------ gradient bookkeeping (build time)
     def grad(self, t):
@@ -511,18 +513,37 @@ class EffDetPlan(RetinaPlan):
         self._zb.zero_()
 
     def _extra_param_grads(self, arena, stream):
+        """Depthwise layers: dW = G * scale, BN gamma / beta gradients (one tiny launch per layer, marshalled once
+        per arena; independent of each other, so they alternate between the two streams)."""
+        calls = self._dw_pg_calls.get(arena) if hasattr(self, '_dw_pg_calls') else None
+        if calls is None:
+            if not hasattr(self, '_dw_pg_calls'):
+                self._dw_pg_calls = {}
+            calls = []
+            for s in self.dw_specs:
+                bn = s.bn
+                calls.append((s.name, (
+                    ptr(s.G_t), ptr(s.conv.weight), ptr(s.scale), ptr(s.colsum if bn is not None else None),
+                    ptr(bn.running_mean if bn is not None else None), ptr(bn.running_var if bn is not None else None),
+                    c_f32(bn.eps if bn is not None else 0.0), c_int(s.C), c_int(s.k),
+                    ptr(self.grad_view(s.conv.weight, arena)),
+                    ptr(self.grad_view(bn.weight, arena) if bn is not None else None),
+                    ptr(self.grad_view(bn.bias, arena) if bn is not None else None), c_int(1))))
+            self._dw_pg_calls[arena] = calls
+            self.keep.append(calls)
         st = c_vp(stream)
-        for s in self.dw_specs:
-            bn = s.bn
-            rc = self.lib.mi355_dw_param_grads(
-                ptr(s.G_t), ptr(s.conv.weight), ptr(s.scale), ptr(s.colsum if bn is not None else None),
-                ptr(bn.running_mean if bn is not None else None), ptr(bn.running_var if bn is not None else None),
-                c_f32(bn.eps if bn is not None else 0.0), c_int(s.C), c_int(s.k),
-                ptr(self.grad_view(s.conv.weight, arena)),
-                ptr(self.grad_view(bn.weight, arena) if bn is not None else None),
-                ptr(self.grad_view(bn.bias, arena) if bn is not None else None), c_int(1), st)
+        side = self._side_stream() if self._side_active() else None
+        if side is not None:
+            ss = c_vp(side.cuda_stream)
+            self.lib.mi355_stream_fork(st, ss)
+        fn = self.lib.mi355_dw_param_grads
+        for i, (name, args) in enumerate(calls):
+            rc = fn(*args, ss if (side is not None and i & 1) else st)
             if rc:
-                raise _lib.Mi355Error('dw_param_grads(%s): %s' % (s.name, self.lib.mi355_last_error().decode()))
+                raise _lib.Mi355Error('dw_param_grads(%s): %s' % (name, self.lib.mi355_last_error().decode()))
+        if side is not None:
+            self._side_dirty = True
+            self.join_side()
 
     def run_heads(self, img):
         self._zf.zero_()
