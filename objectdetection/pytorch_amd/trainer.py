@@ -77,7 +77,12 @@ class Trainer(object):
         order), while the remaining backward launches keep the compute stream busy."""
         from . import engine
         pc = getattr(type(self.model), '_plan_class', None)      # (EfficientDet's tape-built backward: one exchange)
-        return (dp.world(self.group)[1] > 1 and self.overlap and pc is not None and
+        import os
+        # (MI355_FORCE_OVERLAP=1: take this path on a world-size-1 process group too, to rehearse the exchange
+        #  against the real RCCL stream machinery on one GPU: tools/nccl_rehearse.py)
+        multi = dp.world(self.group)[1] > 1 or (os.environ.get('MI355_FORCE_OVERLAP') == '1' and
+                                                torch.distributed.is_available() and torch.distributed.is_initialized())
+        return (multi and self.overlap and pc is not None and
                 pc._build_backward is engine.RetinaPlan._build_backward)
 
     def _allreduce_async(self, t):
@@ -90,10 +95,11 @@ class Trainer(object):
     def _begin(self, img, annot):
         model = self.model
         plan = model._plan(img)
-        # one compute stream beside the collectives: the two-stream schedule and collectives issued between its
-        # launches serialised pathologically in the two-rank rehearsal (gloo on one GPU: 1.2 s per step against
-        # 45 ms single-stream), and an RCCL node was not available to show otherwise
-        plan.use_side = False
+        # one compute stream beside the collectives (MI355_DP_TWO_STREAMS=1 keeps two): rehearsed on a world-size-1
+        # RCCL group (tools/nccl_rehearse.py) the overlapped exchange costs 12.5 ms per step on one compute stream
+        # and 13.2 ms on two; with two gloo ranks time-slicing one GPU the two-stream form degenerated to 1.2 s
+        import os
+        plan.use_side = os.environ.get('MI355_DP_TWO_STREAMS', '0') == '1'
         anchors = model.anchors(img)
         plan.run_heads(img)
         losses = plan.run_loss(anchors, annot)
