@@ -675,7 +675,7 @@ class RetinaPlan(object):
         if rc:
             raise _lib.Mi355Error('param_grads_table: %s' % self.lib.mi355_last_error().decode())
 
-    def backward_segments(self, min_bytes=16 << 20):
+    def backward_segments(self, min_bytes=32 << 20):
         """Cut the backward pass for an overlapped data-parallel exchange: [(n_steps, lo, hi)] in execution
         order, meaning "after the first n_steps backward launches (+ the parameter-gradient table of
         arena range [lo, hi)) the gradients in [lo, hi) are final".  Ranges are cut at top-level module

@@ -17,7 +17,7 @@ from ._lib import c_f32, c_i64, c_int, c_vp, ptr
 class Trainer(object):
     def __init__(self, model, lr=1e-4, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8,
                  clip_norm=0.1, group=None, bucket_bytes=0, graph=False, max_annots=128, overlap=True,
-                 segment_bytes=16 << 20):
+                 segment_bytes=32 << 20):
         """graph=True replays the step from two captured hipGraphs (forward+loss+backward | clip+AdamW;
         the RCCL all-reduce stays between them on the stream): ~400-2000 launches cost one graph
         launch each.  Inputs are copied into static buffers; annotations are padded with -1 rows

@@ -11,11 +11,12 @@ from objectdetection.pytorch_amd.trainer import Trainer
 model, sd = bench.build_model(50, 80, dev)
 img = torch.from_numpy(synth.synth_images(16, 512, 512, seed=1)).to(dev)
 ann = torch.from_numpy(synth.synth_annotations(16, 512, 512, 8, 16, 80, seed=2)).to(dev)
-tr = Trainer(model, lr=1e-4, weight_decay=5e-4, clip_norm=0.1, max_annots=16)
-assert tr._overlap()
+seg = int(os.environ.get('SEG_MB', '16')) << 20
+tr = Trainer(model, lr=1e-4, weight_decay=5e-4, clip_norm=0.1, max_annots=16, segment_bytes=seg,
+             overlap=os.environ.get('MI355_DP_OVERLAP', '1') != '0')
 for _ in range(5): l = tr.step(img, ann)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(20): l = tr.step(img, ann)
 torch.cuda.synchronize()
-print('two_streams=%s overlapped exchange on RCCL (world 1): %.2f ms/step, loss %s' % (os.environ.get('MI355_DP_TWO_STREAMS', '0'), (time.perf_counter() - t0) / 20 * 1e3, l.tolist()), flush=True)
+print('two_streams=%s overlap=%s seg=%s MB: %.2f ms/step, loss %s' % (os.environ.get('MI355_DP_TWO_STREAMS', '0'), tr._overlap(), os.environ.get('SEG_MB', '16'), (time.perf_counter() - t0) / 20 * 1e3, l.tolist()), flush=True)
 dist.destroy_process_group()
