@@ -428,8 +428,17 @@ __global__ __launch_bounds__(256) void param_grads_table_kernel(const Mi355Layer
     for (int i4 = tid * 4; i4 < total; i4 += 1024) {
         const float4* gp = reinterpret_cast<const float4*>(d.G + (long long)k * total + i4);
         float4 g4 = gp[0];
-        for (int sl = 1; sl < d.nslabs; ++sl) {
-            const float4 v = gp[sl * (d.slab_stride >> 2)];
+        const long long ss4 = d.slab_stride >> 2;
+        int sl = 1;
+        for (; sl + 4 <= d.nslabs; sl += 4) {            // four slab loads in flight, added in index order
+            const float4 v0 = gp[sl * ss4], v1 = gp[(sl + 1) * ss4], v2 = gp[(sl + 2) * ss4], v3 = gp[(sl + 3) * ss4];
+            g4.x += v0.x; g4.y += v0.y; g4.z += v0.z; g4.w += v0.w;
+            g4.x += v1.x; g4.y += v1.y; g4.z += v1.z; g4.w += v1.w;
+            g4.x += v2.x; g4.y += v2.y; g4.z += v2.z; g4.w += v2.w;
+            g4.x += v3.x; g4.y += v3.y; g4.z += v3.z; g4.w += v3.w;
+        }
+        for (; sl < d.nslabs; ++sl) {
+            const float4 v = gp[sl * ss4];
             g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
         }
         const float ge[4] = {g4.x, g4.y, g4.z, g4.w};
