@@ -761,7 +761,9 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict_
     float* s_de = sm + C;
     float* s_r = sm + 2 * C;
     float* s_dr = sm + 2 * C + Cse;
-    const int n = blockIdx.x, tid = threadIdx.x;
+    // grid = (image, slice): every block rebuilds the small vectors (de, r, dr: O(C * Cse) MACs), then owns
+    // 1/gridDim.y of the outer-product atomics and of gpool; the bias gradients are added by slice 0 only
+    const int n = blockIdx.x, tid = threadIdx.x, sl_i = blockIdx.y, sl_n = gridDim.y;
     for (int c = tid; c < C; c += 256) {
         s_pool[c] = pool[(long long)n * C + c];
         const float g = gate[(long long)n * C + c];
@@ -769,27 +771,37 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict_
         for (int sl = 0; sl < slabs; ++sl) gg += ggate[((long long)n * slabs + sl) * C + c];   // fixed order
         const float de = gg * g * (1.0f - g);
         s_de[c] = de;
-        atomicAdd(db2 + c, de);
+        if (sl_i == 0) atomicAdd(db2 + c, de);
     }
     for (int j = tid; j < Cse; j += 256) s_r[j] = swishf(rpre[(long long)n * Cse + j]);
     __syncthreads();
-    for (int i = tid; i < C * Cse; i += 256) {
+    const int tot2 = C * Cse;
+    const int lo2 = (int)((long long)tot2 * sl_i / sl_n), hi2 = (int)((long long)tot2 * (sl_i + 1) / sl_n);
+    for (int i = lo2 + tid; i < hi2; i += 256) {
         const int c = i / Cse, j = i - c * Cse;
         atomicAdd(dw2 + i, s_de[c] * s_r[j]);
     }
-    for (int j = tid; j < Cse; j += 256) {
+    // dr[j] = sum_c w2[c][j] * de[c]: 4 threads per j, partial sums through shuffles
+    for (int j0 = 0; j0 < Cse; j0 += 64) {
+        const int j = j0 + (tid >> 2), part = tid & 3;
         float t = 0.0f;
-        for (int c = 0; c < C; ++c) t += w2[c * Cse + j] * s_de[c];
-        const float d = t * dswishf(rpre[(long long)n * Cse + j]);
-        s_dr[j] = d;
-        atomicAdd(db1 + j, d);
+        if (j < Cse)
+            for (int c = part; c < C; c += 4) t += w2[c * Cse + j] * s_de[c];
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        if (j < Cse && part == 0) {
+            const float d = t * dswishf(rpre[(long long)n * Cse + j]);
+            s_dr[j] = d;
+            if (sl_i == 0) atomicAdd(db1 + j, d);
+        }
     }
     __syncthreads();
-    for (int i = tid; i < Cse * C; i += 256) {
+    for (int i = lo2 + tid; i < hi2; i += 256) {       // (same element count: Cse * C)
         const int j = i / C, c = i - j * C;
         atomicAdd(dw1 + i, s_dr[j] * s_pool[c]);
     }
-    for (int c = tid; c < C; c += 256) {
+    const int cl = (int)((long long)C * sl_i / sl_n), ch = (int)((long long)C * (sl_i + 1) / sl_n);
+    for (int c = cl + tid; c < ch; c += 256) {
         float t = 0.0f;
         for (int j = 0; j < Cse; ++j) t += w1[j * C + c] * s_dr[j];
         gpool[(long long)n * C + c] = t;
@@ -801,7 +813,8 @@ extern "C" int mi355_se_fc_bwd(const float* pool, const float* w1, const float* 
                                float* db1, float* dw2, float* db2, int N, int C, int Cse, void* stream) {
     MI355_REQUIRE(pool && w1 && w2 && rpre && gate && ggate && gpool && dw1 && db1 && dw2 && db2 && N > 0 && C > 0 &&
                   Cse > 0, "se_fc_bwd: bad args");
-    hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(N), dim3(256), (size_t)(2 * C + 2 * Cse) * 4, (hipStream_t)stream, pool,
+    const int slices = C >= 256 ? 8 : (C >= 64 ? 4 : 1);
+    hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(N, slices), dim3(256), (size_t)(2 * C + 2 * Cse) * 4, (hipStream_t)stream, pool,
                        w1, w2, rpre, gate, ggate, slabs, gpool, dw1, db1, dw2, db2, C, Cse);
     return check_launch("se_fc_bwd_kernel");
 }
