@@ -201,11 +201,9 @@ class EfficientDet(nn.Module):
             if isinstance(m, nn.BatchNorm2d) and m.training:
                 raise RuntimeError('train-mode BatchNorm is not on the frozen-BN hot path: call freeze_bn()')
         key = (img.shape[0], img.shape[2], img.shape[3], img.device.index)
-        plan = self._plans.get(key)
-        if plan is None or plan.stale():
-            plan = engine_effdet.EffDetPlan(self, img.shape[0], img.shape[2], img.shape[3], img.device)
-            self._plans = {key: plan}
-        return plan
+        from .retinanet import _cached_plan
+        return _cached_plan(self, key, lambda: engine_effdet.EffDetPlan(self, img.shape[0], img.shape[2], img.shape[3],
+                                                                        img.device))
 
     def forward(self, images, annotations=None, return_loss=True, return_head=False):
         """efficientdet.py:528-576 (`return_head` is an extension mirroring RetinaNet's: returns

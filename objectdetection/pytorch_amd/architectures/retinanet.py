@@ -71,6 +71,25 @@ class ClassificationModel(_PlanOnly):
         self.output_act = nn.Sigmoid()
 
 
+def _cached_plan(model, key, build):
+    """Launch plans are cached per (batch, H, W, device): the reference's Resizer / collater hand over a
+    different padded shape almost every batch (datasettool/dataloader.py:655-691, :827-902), and a plan costs
+    seconds to build.  Least-recently-used plans are dropped beyond MI355_MAX_PLANS (default 4; each owns its
+    activations: ~9 GB at R50 512^2 bs16).  A plan whose parameters were re-homed is rebuilt."""
+    import os
+    plans = model._plans
+    plan = plans.pop(key, None)
+    if plan is None or plan.stale():
+        if plan is not None:                          # parameters moved: every cached plan points at dead storage
+            plans.clear()
+        plan = build()
+    plans[key] = plan                                 # (re-)insert as most recently used
+    limit = max(1, int(os.environ.get('MI355_MAX_PLANS', '4')))
+    while len(plans) > limit:
+        plans.pop(next(iter(plans)))
+    return plan
+
+
 class _TrainStep(torch.autograd.Function):
     """(img, annot, *params) -> (cls_loss [1], reg_loss [1]); backward = the HIP backward plan."""
 
@@ -184,11 +203,8 @@ class RetinaNet(nn.Module):
                for m in self.modules()) if not self._plans else False:
             self._channels_last_params()
         key = (img.shape[0], img.shape[2], img.shape[3], img.device.index)
-        plan = self._plans.get(key)
-        if plan is None or plan.stale():
-            plan = self._plan_class(self, img.shape[0], img.shape[2], img.shape[3], img.device)
-            self._plans = {key: plan}             # one live plan: buffers are sized for one shape
-        return plan
+        return _cached_plan(self, key, lambda: self._plan_class(self, img.shape[0], img.shape[2], img.shape[3],
+                                                                img.device))
 
     def forward(self, img_batch, annotations=None, return_head=False, return_loss=True):
         plan = self._plan(img_batch)

@@ -188,3 +188,23 @@ def test_three_level_variants_vs_reference_golden(golden_dir, dev, tag):
     np.testing.assert_allclose(s[:top].cpu().numpy(), ref_s[:top], rtol=0.1, atol=2e-2)
     assert abs(s.numel() - len(ref_s)) <= max(3, len(ref_s) // 5)
     assert c.dtype == torch.int64 and b.shape == (s.numel(), 4)
+
+
+def test_plan_cache_keeps_several_shapes(golden_dir, dev):
+    """The reference's collater pads every batch to its own max shape (dataloader.py:655-691): alternating
+    shapes must reuse their launch plans (LRU, MI355_MAX_PLANS) instead of rebuilding one per batch, and the
+    losses of a shape must not depend on what ran in between."""
+    g, model, img, ann, _ = _build('r18_256', golden_dir, dev)
+    small = img[:, :, :128, :192].contiguous()
+    ann_s = ann.clone()
+    ann_s[..., :4] = ann_s[..., :4].clamp(max=120.0)
+    with torch.no_grad():
+        a1 = [t.clone() for t in model(img, ann)]
+        pa = model._plans[(img.shape[0], 256, 256, dev.index)]
+        b1 = [t.clone() for t in model(small, ann_s)]
+        pb = model._plans[(img.shape[0], 128, 192, dev.index)]
+        a2 = model(img, ann)
+        b2 = model(small, ann_s)
+    assert model._plans[(img.shape[0], 256, 256, dev.index)] is pa and model._plans[(img.shape[0], 128, 192, dev.index)] is pb
+    assert len(model._plans) == 2
+    assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1]) and torch.equal(b1[0], b2[0]) and torch.equal(b1[1], b2[1])
