@@ -717,7 +717,8 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         return e ? atoi(e) : 3;                        // 0 off, 1 K <= 64 only, 2 every launch, 3 auto
     }();
     const int taps0 = in.prob[0].TR * in.prob[0].TS;
-    const bool wide_wins = taps0 >= 9 && C >= 128 && grid128 >= 1024;
+    static const int wide_min_grid = [] { const char* e = getenv("MI355_WIDE_MIN_GRID"); return e ? atoi(e) : 1024; }();
+    const bool wide_wins = taps0 >= 9 && C >= 128 && grid128 >= wide_min_grid;
     const bool narrow = !splitk && ((narrow_mode == 1 && in.K <= 64) || narrow_mode == 2 ||
                                     (narrow_mode == 3 && (in.K <= 64 || !wide_wins)));
     if (narrow) grid128 = grid128 / cdiv(in.K, BN) * cdiv(in.K, 64);

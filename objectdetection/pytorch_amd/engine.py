@@ -346,7 +346,7 @@ class RetinaPlan(object):
         slab = spec.Kpad * spec.T * spec.Cpad
         tiles = ops_conv.wgrad_tiles(spec.Kpad, spec.Cpad, spec.T, problems)
         split = pick_split_rows(rows, tiles, target_blocks=int(os.environ.get('MI355_WG_BLOCKS', '512')),
-                                min_rows=int(os.environ.get('MI355_WG_MINROWS', '512')),
+                                min_rows=int(os.environ.get('MI355_WG_MINROWS', '1024')),
                                 granule=int(os.environ.get('MI355_WG_GRANULE', '64')))
         self.keep.append(L)
         spec._wgrad_launch = L

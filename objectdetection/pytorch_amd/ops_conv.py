@@ -162,7 +162,8 @@ def wgrad_tiles(kpad, cpad, taps, problems=None):
 def pick_split_rows(total_rows, tiles_per_chunk, target_blocks=512, min_rows=512, granule=64):
     """Rows of the pixel reduction per block: ~2 four-wave blocks per CU, but never so few rows that
     the partial-tile epilogue (64 KiB per block) outweighs the MFMA work.  (Measured on R50 512^2
-    bs16: 512 blocks / 512 rows beats 256..1024 blocks; one eight-wave block per CU with two row
+    bs16: 512 blocks beat 256..1024; with the slabs summed by the table kernel a 1024-row floor
+    (the engine's default) beats 512..2048 by 1-2 %; one eight-wave block per CU with two row
     groups, MI355_WG_GROUPS=2 + granule 128, halves the slabs but runs 2 % slower end to end.)"""
     chunks = max(1, target_blocks // max(1, tiles_per_chunk))
     rows = -(-total_rows // chunks)
