@@ -145,3 +145,19 @@ def test_efficientdet_end_to_end(golden_dir, tag):
     assert s.shape == tuple(g['det_scores'].shape)
     np.testing.assert_allclose(s.numpy(), g['det_scores'], rtol=1e-4)
     np.testing.assert_allclose(b.numpy(), g['det_boxes'], rtol=1e-3, atol=1e-2)
+
+
+def test_input_side_normalizer_collater(golden_dir):
+    """a-0 / f-2: the numpy restatement of load scaling + Normalizer + collater against the reference's own
+    output (datasettool/dataloader.py:92, :905-924, :655-691), bit for bit."""
+    from oracle import ref_input
+    g = np.load(os.path.join(golden_dir, 'input.npz'))
+    imgs = [g['u8_%d' % i] for i in range(4)]
+    anns = [g['ann_%d' % i] for i in range(4)]
+    img, ann = ref_input.collate([ref_input.normalize(ref_input.load_scale(i)) for i in imgs], anns)
+    assert img.dtype == np.float32 and np.array_equal(img, g['img'])
+    assert np.array_equal(ann, g['annot'])
+    _, ann0 = ref_input.collate([ref_input.normalize(ref_input.load_scale(i)) for i in imgs[:2]],
+                                [np.zeros((0, 5))] * 2)
+    assert np.array_equal(ann0, g['annot_all_empty'])
+    assert img[2, :, 1:, :].max() == 0.0 and img[2, :, 0, 1:].max() == 0.0      # the 1x1 image: zero padding

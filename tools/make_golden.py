@@ -245,6 +245,48 @@ def gen_postprocess():
     print('postprocess: images', len(out), [o['scores'].shape for o in out], 'all-empty list length', len(out0))
 
 
+def input_samples():
+    """Seeded ragged batch for the input-side golden: decoded uint8 images + float64 annotation rows."""
+    rng = np.random.default_rng(123)
+    sizes = [(37, 53), (64, 40), (1, 1), (48, 64)]
+    imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+    imgs[0][0, 0] = (0, 255, 128)
+    counts = [3, 0, 1, 5]
+    annots = [np.concatenate([rng.random((m, 4)) * 60.0, rng.integers(0, 80, size=(m, 1)).astype(np.float64)], axis=1)
+              for m in counts]
+    return imgs, annots
+
+
+def gen_input():
+    """Input side (a-0 / f-2): datasettool/dataloader.py `Normalizer` (:905-924) + `collater` (:655-691) run as
+    they are.  The module imports torchvision.transforms, skimage and the dataset tools at the top for its
+    dataset / resampling classes; none is installed and none is touched by these two: empty stand-in modules
+    let the file import."""
+    for name in ('torchvision.transforms', 'torchvision.utils', 'skimage', 'skimage.io', 'skimage.transform',
+                 'skimage.color', 'datasettool.ksevendata_tool', 'pycocotools', 'pycocotools.coco', 'cv2'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    sys.modules['torchvision'].utils = sys.modules['torchvision.utils']
+    sys.modules['datasettool.ksevendata_tool'].KSevenData = object
+    sys.modules['pycocotools.coco'].COCO = object
+    from datasettool import dataloader as ref_dl
+    imgs, annots = input_samples()
+    norm = ref_dl.Normalizer()
+    data = []
+    for im, an in zip(imgs, annots):
+        s = norm({'img': im.astype(np.float32) / 255.0, 'annot': an.copy(), 'scale': 1.0})     # :92 then Normalizer
+        data.append({'img': torch.from_numpy(s['img']), 'annot': torch.from_numpy(s['annot']), 'scale': s['scale']})
+    out = ref_dl.collater(data)
+    d = dict(img=out['img'].numpy(), annot=out['annot'].numpy())
+    for i, (im, an) in enumerate(zip(imgs, annots)):
+        d['u8_%d' % i], d['ann_%d' % i] = im, an
+    empty = ref_dl.collater([{'img': dd['img'], 'annot': torch.zeros(0, 5, dtype=torch.float64), 'scale': 1.0} for dd in data[:2]])
+    d['annot_all_empty'] = empty['annot'].numpy()
+    np.savez_compressed(os.path.join(OUT, 'input.npz'), **d)
+    print('input: img', d['img'].shape, d['img'].dtype, 'annot', d['annot'].shape, 'all-empty', d['annot_all_empty'].shape)
+
+
 # ---------------------------------------------------------------- end to end RetinaNet (a-1..a-4)
 def load_synth(model, depth, num_classes, gain):
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -427,7 +469,7 @@ def gen_e2e_effdet(coef, H, W, B, num_classes, tag, gain, head_std):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['anchors', 'loss', 'decode', 'e2e', 'effdet', 'variants', 'postprocess']
+    which = sys.argv[1:] or ['anchors', 'loss', 'decode', 'e2e', 'effdet', 'variants', 'postprocess', 'input']
     if 'anchors' in which:
         gen_anchors()
     if 'loss' in which:
@@ -436,6 +478,8 @@ if __name__ == '__main__':
         gen_decode()
     if 'postprocess' in which:
         gen_postprocess()
+    if 'input' in which:
+        gen_input()
     if 'variants' in which:
         gen_e2e_variant('tiny', 64, 96, 2, 12, 'tiny_64x96', 0.9)
         gen_e2e_variant('p45p6', 192, 288, 1, 12, 'p45p6_192x288', 0.87)
