@@ -208,3 +208,57 @@ def test_plan_cache_keeps_several_shapes(golden_dir, dev):
     assert model._plans[(img.shape[0], 256, 256, dev.index)] is pa and model._plans[(img.shape[0], 128, 192, dev.index)] is pb
     assert len(model._plans) == 2
     assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1]) and torch.equal(b1[0], b2[0]) and torch.equal(b1[1], b2[1])
+
+
+def test_coco_result_writer(tmp_path, monkeypatch):
+    """f-4: datasettool/coco_eval.py:6-63 over the device decode path: scale correction, xywh, threshold break,
+    category mapping, JSON file."""
+    import json
+    from objectdetection.pytorch_amd.architectures import retinanet
+    from objectdetection.pytorch_amd.datasettool import coco_eval
+    dev = torch.device('cuda', 0)
+    model = retinanet.retinanet(18, num_classes=8)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=0.87)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+
+    class DS:
+        set_name = 'val_synth'
+        image_ids = [11, 42, 7]
+        coco = None
+
+        def __len__(self):
+            return 3
+
+        def __getitem__(self, i):
+            im = synth.synth_images(1, 128, 160, seed=30 + i)[0].transpose(1, 2, 0).copy()       # HWC, as the datasets give
+            return {'img': torch.from_numpy(im), 'scale': [0.5, 1.25, 1.0][i]}
+
+        def label_to_coco_label(self, label):
+            return 100 + label
+
+    ds = DS()
+    monkeypatch.chdir(tmp_path)
+    model.eval()
+    s0 = model(ds[0]['img'].permute(2, 0, 1).to(dev).unsqueeze(0), return_loss=False)[0]
+    thr = float(s0.median())                                  # cuts every image's sorted list somewhere inside
+    got = coco_eval.evaluate_coco(ds, model, threshold=thr)
+    assert model.training                                     # coco_eval.py:78
+    want = []
+    model.eval()
+    for i in range(3):
+        d = ds[i]
+        s, l, b = model(d['img'].permute(2, 0, 1).to(dev).unsqueeze(0), return_loss=False)
+        s, l, b = s.cpu(), l.cpu(), b.cpu() / d['scale']
+        for k in range(b.shape[0]):
+            if float(s[k]) < thr:
+                break
+            want.append({'image_id': ds.image_ids[i], 'category_id': 100 + int(l[k]), 'score': float(s[k]),
+                         'bbox': [float(b[k, 0]), float(b[k, 1]), float(b[k, 2] - b[k, 0]), float(b[k, 3] - b[k, 1])]})
+    assert len(want) > 0 and len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g['image_id'] == w['image_id'] and g['category_id'] == w['category_id'] and g['score'] == w['score']
+        assert g['bbox'] == w['bbox']
+    on_disk = json.load(open(tmp_path / 'val_synth_bbox_results.json'))
+    assert on_disk == got
