@@ -27,6 +27,10 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
 
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# HIP spreads a process's streams over GPU_MAX_HW_QUEUES (default 4) hardware queues; once RCCL has made
+# its own streams the plan's second compute stream lands on the first one's queue and the two serialise
+# (12.8 instead of 10.9 ms per step, tools/nccl_rehearse.py).  Must be set before the HIP runtime starts.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import numpy as np          # noqa: E402
 import torch                # noqa: E402

@@ -95,11 +95,16 @@ class Trainer(object):
     def _begin(self, img, annot):
         model = self.model
         plan = model._plan(img)
-        # one compute stream beside the collectives (MI355_DP_TWO_STREAMS=1 keeps two): rehearsed on a world-size-1
-        # RCCL group (tools/nccl_rehearse.py) the overlapped exchange costs 12.5 ms per step on one compute stream
-        # and 13.2 ms on two; with two gloo ranks time-slicing one GPU the two-stream form degenerated to 1.2 s
+        # RCCL: the two compute streams stay (weight gradients beside data gradients) and each range is handed to
+        # the collective from the stream it is final on.  Needs GPU_MAX_HW_QUEUES >= 8 (set on package import):
+        # with HIP's default of 4 hardware queues RCCL's streams push both compute streams onto one queue
+        # (world-size-1 RCCL rehearsal, tools/nccl_rehearse.py: 11.0 ms per step against 13.1 ms, 12.4 ms on
+        # one compute stream).  gloo (CPU tests) moves tensors through the host and synchronises streams: one
+        # compute stream there (two gloo ranks time-slicing one GPU degenerated to 1.2 s per step on two).
         import os
-        plan.use_side = os.environ.get('MI355_DP_TWO_STREAMS', '0') == '1'
+        import torch.distributed as dist
+        two = os.environ.get('MI355_DP_TWO_STREAMS', '1' if dist.get_backend(self.group) == 'nccl' else '0')
+        plan.use_side = two == '1'
         anchors = model.anchors(img)
         plan.run_heads(img)
         losses = plan.run_loss(anchors, annot)
