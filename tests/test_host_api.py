@@ -110,3 +110,16 @@ def test_efficientdet_state_dict_matches_reference(golden_dir, tag, coef):
         model(torch.zeros(1, 3, 128, 128), torch.zeros(1, 1, 5))          # no CPU fallback
     with pytest.raises(RuntimeError):
         efficientdet.EfficientDet(num_classes=3, compound_coef=0, load_weights=True)   # never fetch
+
+
+def test_wgrad_split_rows_are_whole_granules():
+    """conv_wgrad takes pixel chunks in multiples of 64 rows whatever the layer size (the relaxed floor for
+    launches that would leave CUs without a block included)."""
+    from objectdetection.pytorch_amd.ops_conv import pick_split_rows
+    for total in (1, 63, 64, 1000, 1024, 4096, 16 * 40 * 40, 16 * 64 * 64 + 7, 8 * 96 * 96, 16 * 256 * 256):
+        for tiles in (1, 2, 3, 5, 16, 24, 72, 144):
+            for floor in (512, 1024):
+                rows = pick_split_rows(total, tiles, 512, floor, 64)
+                assert rows % 64 == 0 and rows >= 256, (total, tiles, floor, rows)
+    assert pick_split_rows(16 * 64 * 64, 1, 512, 1024, 64) == 256        # one small tile: a block per CU
+    assert pick_split_rows(16 * 32 * 32, 16, 512, 1024, 64) == 1024       # enough tiles: the floor stands

@@ -1,5 +1,5 @@
 """How far apart do the two compute streams finish?  Events at every join_side(): time since the previous join
-at which the main stream and the side stream were done.  python tools/side_balance.py"""
+at which the main stream and the side stream were done.  python tools/side_balance.py [efficientdet-d0]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -7,7 +7,8 @@ import torch
 import bench, synth
 from objectdetection.pytorch_amd.trainer import Trainer
 dev = torch.device('cuda', 0)
-model, sd = bench.build_model(50, 80, dev)
+arch = sys.argv[1] if len(sys.argv) > 1 else 'retinanet'
+model, sd = bench.build_model(50, 80, dev, arch)
 img = torch.from_numpy(synth.synth_images(16, 512, 512, seed=1)).to(dev)
 ann = torch.from_numpy(synth.synth_annotations(16, 512, 512, 8, 16, 80, seed=2)).to(dev)
 tr = Trainer(model, lr=1e-4, weight_decay=5e-4, clip_norm=0.1, max_annots=16)
