@@ -651,6 +651,7 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const unsigned short* __
         const int ph = tid / min(c8n, 256);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (c8 < c8n && ph < nphase) {
+#pragma unroll 4
             for (int m = r0 + ph; m < r1; m += nphase) {
                 float v[8];
                 load8(z + ((long long)n * HW + m) * C + c8 * 8, v);
@@ -735,6 +736,7 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pa
     const int n = blockIdx.x, tid = threadIdx.x;
     for (int c = tid; c < C; c += 256) {
         float t = 0.0f;
+#pragma unroll 8
         for (int sl = 0; sl < slabs; ++sl) t += part[((long long)n * slabs + sl) * C + c];   // fixed order
         s_pool[c] = t;
         pool[(long long)n * C + c] = t;
@@ -792,6 +794,7 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict_
         s_pool[c] = pool[(long long)n * C + c];
         const float g = gate[(long long)n * C + c];
         float gg = 0.0f;
+#pragma unroll 8
         for (int sl = 0; sl < slabs; ++sl) gg += ggate[((long long)n * slabs + sl) * C + c];   // fixed order
         const float de = gg * g * (1.0f - g);
         s_de[c] = de;
