@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_s1_kernel(const unsigned short
 // 16-B cells (consecutive lanes = consecutive cells: conflict-free ds_read_b128), the taps' weights sit in
 // LDS too, and the outputs go back through LDS so that a pixel's NC8 chunks are stored contiguously.
 constexpr int DT_TH = 8, DT_TW = 32;
-template <int K, bool FLIP>
+template <int K, bool FLIP, bool INSW = false>
 __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* __restrict__ in, const float* __restrict__ w_t,
                                                          const float* __restrict__ bias, unsigned short* __restrict__ out,
                                                          const unsigned short* __restrict__ zin, int accumulate,
@@ -162,6 +162,10 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* _
         s8v v = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
         if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W)
             v = *reinterpret_cast<const s8v*>(in + (((long long)n * H + h) * W + w) * C + (c8b + ch) * 8);
+        if (INSW) {                                        // input stored as pre-activation z: swish once per loaded
+#pragma unroll                                             // element, rounded to bf16 like a materialised swish(z)
+            for (int e = 0; e < 8; ++e) v[e] = (short)f32_to_bf16_rn(swishf(bf16_to_f32((unsigned short)v[e])));
+        }
         tile[ch * NPX + px] = v;
     }
     for (int i = tid; i < K * K * nc8 * 8; i += 256) {
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* _
     }
 }
 
-template <int K, bool FLIP>
+template <int K, bool FLIP, bool INSW = false>
 static int launch_dw_tile(const void* in, const float* w_t, const float* bias, void* out, const void* zin, int accumulate,
                           int N, int H, int W, int C, int pad_t, int pad_l, void* stream) {
     const int c8n = C / 8;
@@ -238,10 +242,10 @@ static int launch_dw_tile(const void* in, const float* w_t, const float* bias, v
     const dim3 grid((unsigned)((W + DT_TW - 1) / DT_TW), (unsigned)((H + DT_TH - 1) / DT_TH), (unsigned)(N * (c8n / nc8)));
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)dw_tile_s1_kernel<K, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)dw_tile_s1_kernel<K, FLIP, INSW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((dw_tile_s1_kernel<K, FLIP>), grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short*)in, w_t,
+    hipLaunchKernelGGL((dw_tile_s1_kernel<K, FLIP, INSW>), grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short*)in, w_t,
                        bias, (unsigned short*)out, (const unsigned short*)zin, accumulate, N, H, W, C, nc8, pad_t, pad_l);
     return check_launch("dw_tile_s1_kernel");
 }
@@ -251,9 +255,13 @@ extern "C" int mi355_dwconv_fwd(const void* in, int in_swish, const float* w_t, 
                                 void* stream) {
     MI355_REQUIRE(in && w_t && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && k > 0 && stride > 0,
                   "dwconv_fwd: bad args");
-    if (stride == 1 && !in_swish && (k == 3 || k == 5) && P == H && Q == W && W >= 16 && H >= 8)
+    if (stride == 1 && (k == 3 || k == 5) && P == H && Q == W && W >= 16 && H >= 8) {
+        if (in_swish)
+            return k == 3 ? launch_dw_tile<3, false, true>(in, w_t, bias, out, nullptr, 0, N, H, W, C, pad_t, pad_l, stream)
+                          : launch_dw_tile<5, false, true>(in, w_t, bias, out, nullptr, 0, N, H, W, C, pad_t, pad_l, stream);
         return k == 3 ? launch_dw_tile<3, false>(in, w_t, bias, out, nullptr, 0, N, H, W, C, pad_t, pad_l, stream)
                       : launch_dw_tile<5, false>(in, w_t, bias, out, nullptr, 0, N, H, W, C, pad_t, pad_l, stream);
+    }
     if (stride == 1 && !in_swish && (k == 3 || k == 5) && P == H && Q == W) {
         const long long tot4 = (long long)N * P * ((Q + 3) / 4) * (C / 8);
         if (k == 3)
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(
 // block = 32 (kernel row, chunk) items x 8 row lanes; lanes reduced through LDS, one atomic per (tap, channel).
 // 8 (kernel row, chunk) items x 32 row lanes: layers have k * C/8 = 6 .. 432 items, blocks of 8 leave few idle
 constexpr int DW_U = 8, DW1_IPB = 8, DW1_PL = 32;
-template <int K>
+template <int K, bool INSW = false>
 __global__ __launch_bounds__(256) void dwconv_wgrad_s1_kernel(
     const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy, float* __restrict__ dw_t,
     float* __restrict__ colsum, int N, int H, int W, int C, int pad_t, int pad_l, int P, int Q, int rows_per_block,
@@ -462,8 +470,13 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_s1_kernel(
 #pragma unroll
             for (int b = 0; b < K - 1; ++b) {
                 const int w = qa + b - pad_l;             // window of output pixel q = qa, all but the last tap
-                if (row_ok && (unsigned)w < (unsigned)W) load8(xr + (long long)w * C, win[b + 1]);
-                else {
+                if (row_ok && (unsigned)w < (unsigned)W) {
+                    load8(xr + (long long)w * C, win[b + 1]);
+                    if (INSW) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) win[b + 1][e] = bf16_to_f32(f32_to_bf16_rn(swishf(win[b + 1][e])));
+                    }
+                } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) win[b + 1][e] = 0.0f;
                 }
@@ -490,6 +503,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_s1_kernel(
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         win[K - 1][e] = bf16_to_f32((unsigned short)xraw[u][e]);
+                        if (INSW) win[K - 1][e] = bf16_to_f32(f32_to_bf16_rn(swishf(win[K - 1][e])));   // x is z
                         g[e] = bf16_to_f32((unsigned short)graw[u][e]);
                     }
                     if (do_cs) {
@@ -542,7 +556,7 @@ extern "C" int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, f
                                   void* stream) {
     MI355_REQUIRE(x && dy && dw_t && N > 0 && C > 0 && C % 8 == 0 && k > 0, "dwconv_wgrad: bad args");
     const int nrows = N * P;
-    if (stride == 1 && !in_swish && (k == 3 || k == 5) && P == H && Q == W) {
+    if (stride == 1 && (k == 3 || k == 5) && P == H && Q == W) {
         const int items = k * (C / 8);
         const int bx = (items + DW1_IPB - 1) / DW1_IPB;
         const int qseg = 32, bz = (Q + qseg - 1) / qseg;      // column segments: a thread walks <= 32 pixels of a row
@@ -553,12 +567,13 @@ extern "C" int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, f
         rows = (rows + DW1_PL - 1) / DW1_PL * DW1_PL;           // whole lane groups of rows
         const int by = (nrows + rows - 1) / rows;
         dim3 grid((unsigned)bx, (unsigned)by, (unsigned)bz);
-        if (k == 3)
-            hipLaunchKernelGGL(dwconv_wgrad_s1_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
-                               (const unsigned short*)dy, dw_t, colsum, N, H, W, C, pad_t, pad_l, P, Q, rows, qseg);
-        else
-            hipLaunchKernelGGL(dwconv_wgrad_s1_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
-                               (const unsigned short*)dy, dw_t, colsum, N, H, W, C, pad_t, pad_l, P, Q, rows, qseg);
+#define MI355_DW1(KK, SW)                                                                                          \
+    hipLaunchKernelGGL((dwconv_wgrad_s1_kernel<KK, SW>), grid, dim3(256), 0, (hipStream_t)stream,                    \
+                       (const unsigned short*)x, (const unsigned short*)dy, dw_t, colsum, N, H, W, C, pad_t, pad_l, \
+                       P, Q, rows, qseg)
+        if (k == 3) { if (in_swish) MI355_DW1(3, true); else MI355_DW1(3, false); }
+        else        { if (in_swish) MI355_DW1(5, true); else MI355_DW1(5, false); }
+#undef MI355_DW1
         return check_launch("dwconv_wgrad_s1_kernel");
     }
     const int items = k * k * (C / 8);

@@ -185,20 +185,24 @@ class EffDetPlan(RetinaPlan):
         out = self.new((N, P, Q, C))
         geo = (c_int(N), c_int(H), c_int(W), c_int(C), c_int(spec.k), c_int(spec.stride), c_int(pt), c_int(pl),
                c_int(P), c_int(Q))
-        xs = x
-        if x_swish:
-            # swish ONCE per element (one elementwise pass, kept for the weight gradient) instead of once per
-            # tap inside the 9- / 25-tap loop of the depthwise kernel: the expf dominated that kernel
+        xs, insw = x, 0
+        if x_swish and spec.stride == 1:
+            # stride 1: the LDS-tiled forward and the sliding-window weight gradient apply swish as they load
+            # (once per loaded element, rounded to bf16: bit-identical to a materialised swish(z))
+            insw = 1
+        elif x_swish:
+            # stride 2 (per-tap kernels): swish ONCE per element in one elementwise pass, kept for the weight
+            # gradient, instead of once per tap inside the 9- / 25-tap loop: the expf dominated that kernel
             xs = self.new(tuple(x.shape))
             self._step(self.fwd_steps, 'mi355_swish_bf16', ptr(x), ptr(xs), c_i64(x.numel()))
-        self._step(self.fwd_steps, 'mi355_dwconv_fwd', ptr(xs), c_int(0), ptr(spec.w_t), ptr(spec.shift),
+        self._step(self.fwd_steps, 'mi355_dwconv_fwd', ptr(xs), c_int(insw), ptr(spec.w_t), ptr(spec.shift),
                    ptr(out), *geo)
 
         def bwd():
             if not self.has_grad(out):
                 return
             dy = self.grad(out)
-            self._step(self.bwd_steps, 'mi355_dwconv_wgrad', ptr(xs), c_int(0), ptr(dy), ptr(spec.G_t),
+            self._step(self.bwd_steps, 'mi355_dwconv_wgrad', ptr(xs), c_int(insw), ptr(dy), ptr(spec.G_t),
                        ptr(spec.colsum if spec.bn is not None else None), *geo)
             dx = self.grad(x)
             acc = not self.first_write(x)
