@@ -246,47 +246,73 @@ extern "C" int mi355_maxpool3x3s2_fwd(const void* in, void* out, int8_t* idx, in
     return check_launch("maxpool_fwd_kernel");
 }
 
+// A thread owns the 2 x 2 input block (2p', 2q') of one 8-channel chunk: the block lies in the windows
+// (p'+a, q'+b), a, b in {0, 1}, whose (argmax, gradient) cells are loaded ONCE for the four pixels (a thread per
+// input pixel loaded 2.25 cells per pixel on average).  Window (p, q) covers rows 2p-1 .. 2p+1: pixel row
+// 2p'+dh sits at window row dh + 1 - 2a, likewise for columns; contributions are added in (p, q) order.
 __global__ void maxpool_bwd_kernel(const unsigned short* __restrict__ gout, const signed char* __restrict__ idx,
                                    unsigned short* __restrict__ gin, const unsigned short* __restrict__ relu_mask,
                                    int N, int H, int W, int C, int P, int Q) {
     const int c8n = C >> 3;
+    const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)N * H * W * c8n;
-    if (t >= total) return;
+    if (t >= (long long)N * H2 * W2 * c8n) return;
     const int c8 = (int)(t % c8n);
     long long r = t / c8n;
-    const int w = (int)(r % W);  r /= W;
-    const int h = (int)(r % H);
-    const int n = (int)(r / H);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int p_lo = max(0, h / 2), p_hi = min(P - 1, (h + 1) / 2);       // 2p-1 <= h <= 2p+1
-    const int q_lo = max(0, w / 2), q_hi = min(Q - 1, (w + 1) / 2);
-    for (int p = p_lo; p <= p_hi; ++p)
-        for (int q = q_lo; q <= q_hi; ++q) {
-            const int slot = (h - (2 * p - 1)) * 3 + (w - (2 * q - 1));
+    const int q2 = (int)(r % W2);  r /= W2;
+    const int p2 = (int)(r % H2);
+    const int n = (int)(r / H2);
+    float acc[2][2][8];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) (&acc[0][0][0])[i] = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int p = p2 + a, q = q2 + b;
+            if (p >= P || q >= Q) continue;
             const long long o = (((long long)n * P + p) * Q + q) * C + c8 * 8;
             const unsigned long long pk = *reinterpret_cast<const unsigned long long*>(idx + o);
             const s8v g = *reinterpret_cast<const s8v*>(gout + o);
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if ((int)((pk >> (8 * e)) & 0xff) == slot) acc[e] += bf16_to_f32((unsigned short)g[e]);
+            for (int dh = 0; dh < 2; ++dh) {
+                const int wr = dh + 1 - 2 * a;                 // window row of input row 2p'+dh
+                if (wr < 0) continue;
+#pragma unroll
+                for (int dw = 0; dw < 2; ++dw) {
+                    const int wc = dw + 1 - 2 * b;
+                    if (wc < 0) continue;
+                    const int slot = wr * 3 + wc;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if ((int)((pk >> (8 * e)) & 0xff) == slot) acc[dh][dw][e] += bf16_to_f32((unsigned short)g[e]);
+                }
+            }
         }
-    if (relu_mask) {
-        const s8v m = *reinterpret_cast<const s8v*>(relu_mask + t * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (!(bf16_to_f32((unsigned short)m[e]) > 0.0f)) acc[e] = 0.0f;
-    }
-    s8v o;
+    for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(acc[e]);
-    *reinterpret_cast<s8v*>(gin + t * 8) = o;
+        for (int dw = 0; dw < 2; ++dw) {
+            const int h = 2 * p2 + dh, w = 2 * q2 + dw;
+            if (h >= H || w >= W) continue;
+            const long long o = ((((long long)n * H + h) * W + w) * c8n + c8) * 8;
+            if (relu_mask) {
+                const s8v m = *reinterpret_cast<const s8v*>(relu_mask + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (!(bf16_to_f32((unsigned short)m[e]) > 0.0f)) acc[dh][dw][e] = 0.0f;
+            }
+            s8v v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (short)f32_to_bf16_rn(acc[dh][dw][e]);
+            *reinterpret_cast<s8v*>(gin + o) = v;
+        }
 }
 
 extern "C" int mi355_maxpool3x3s2_bwd(const void* gout, const int8_t* idx, void* gin, const void* relu_mask,
                                       int N, int H, int W, int C, void* stream) {
     MI355_REQUIRE(gout && idx && gin && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_bwd: bad args");
     const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
-    const long long total = (long long)N * H * W * (C / 8);
+    const long long total = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)gout, (const signed char*)idx, (unsigned short*)gin,
                        (const unsigned short*)relu_mask, N, H, W, C, P, Q);

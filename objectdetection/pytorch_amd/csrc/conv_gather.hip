@@ -25,8 +25,7 @@ namespace {
 
 constexpr int BN = 128, BK = 64;
 constexpr int EPI_LD = BN + 4;                           // fp32 staging row stride (floats): 64-row halves
-constexpr int EPI16_LD = BN + 4;                         // bf16 staging row stride (elements), 264 B
-constexpr int EPI_BYTES = 64 * EPI_LD * 4;               // 33792 B = 128 * EPI16_LD * 2 as well
+constexpr int EPI_BYTES = 64 * EPI_LD * 4;               // 33792 B (the bf16 staging, 128 rows of BN + 4 elements, is the same size)
 
 struct ProbDev {
     const unsigned short* in;

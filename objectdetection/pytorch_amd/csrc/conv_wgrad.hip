@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
 // LDS image of the activation tile: 128-B rows, 16-B chunk c at position c ^ (gx(row) << 1),
 // gx(row) = bit1(row) | bit3(row) << 1: the 8 rows of a 32-lane half of a transposed read (any of the
 // three shifts) land in 8 distinct 32-B bank groups.
-constexpr int R3_TC = 64, R3_XROWS = 72, R3_DY_BYTES = RM * TK * 2, R3_X_BYTES = R3_XROWS * R3_TC * 2;
+constexpr int R3_TC = 64, R3_XROWS = 72, R3_DY_BYTES = RM * TK * 2;      // x tile: R3_XROWS * R3_TC * 2 bytes
 constexpr int R3_STAGE = 26624;                           // 16384 + 9216, 1 KiB aligned
 constexpr int R3_TABN = 520, R3_TAB_OFF = 2 * R3_STAGE;
 constexpr int R3_EPI_LD = R3_TC + 4;

@@ -123,3 +123,20 @@ def test_wgrad_split_rows_are_whole_granules():
                 assert rows % 64 == 0 and rows >= 256, (total, tiles, floor, rows)
     assert pick_split_rows(16 * 64 * 64, 1, 512, 1024, 64) == 256        # one small tile: a block per CU
     assert pick_split_rows(16 * 32 * 32, 16, 512, 1024, 64) == 1024       # enough tiles: the floor stands
+
+
+def test_package_import_raises_hw_queue_count():
+    """The two compute streams of a plan need their own hardware queues beside RCCL's streams: importing the
+    package sets GPU_MAX_HW_QUEUES (read when the HIP runtime starts) unless the user already chose a value."""
+    import subprocess
+    import sys
+    code = ("import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import objectdetection.pytorch_amd; "
+            "print(os.environ['GPU_MAX_HW_QUEUES'])")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert int(out.stdout.strip()) >= 8
+    code = ("import os; os.environ['GPU_MAX_HW_QUEUES'] = '5'; import objectdetection.pytorch_amd; "
+            "print(os.environ['GPU_MAX_HW_QUEUES'])")
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip() == '5'
