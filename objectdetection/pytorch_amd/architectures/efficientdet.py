@@ -145,9 +145,6 @@ class EfficientDet(nn.Module):
         my_ratios = np.array([1, 2])
         my_scales = np.array([2 ** 0, 2 ** (1.0 / 3.0), 2 ** (2.0 / 3.0)])
         num_anchors = len(my_ratios) * len(my_scales)
-        if compound_coef >= 6:
-            raise NotImplementedError('D6/D7 use the plain (non-attention) BiFPN sum (efficientdet.py:269-317): '
-                                      'not built in the HIP plan yet')
         self.bifpn = nn.Sequential(*[BiFPN(self.fpn_num_filters[compound_coef], conv_channel_coef[compound_coef],
                                            True if i == 0 else False, attention=True if compound_coef < 6 else False)
                                      for i in range(self.fpn_cell_repeats[compound_coef])])

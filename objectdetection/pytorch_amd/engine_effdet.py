@@ -265,9 +265,15 @@ class EffDetPlan(RetinaPlan):
 
     def node_op(self, param, in0, in1, up1, in2=None):
         """z = w0*in0 + w1*in1' (+ w2*in2), w = relu(p)/(sum relu(p) + 1e-4) (efficientdet.py:213-265)."""
-        n = param.numel()
-        w = self.new((4,), torch.float32, zero=True)
-        self._step(self.prep_steps, 'mi355_fusion_weights_fwd', ptr(param), c_int(n), c_f32(1e-4), ptr(w))
+        if param is None:
+            # plain sum of the inputs (`_forward`, efficientdet.py:269-317: D6 / D7): unit weights, no parameter
+            if getattr(self, '_unit_w', None) is None:
+                self._unit_w = torch.ones(4, dtype=torch.float32, device=self.dev)
+            w = self._unit_w
+        else:
+            n = param.numel()
+            w = self.new((4,), torch.float32, zero=True)
+            self._step(self.prep_steps, 'mi355_fusion_weights_fwd', ptr(param), c_int(n), c_f32(1e-4), ptr(w))
         N, H, W, C = in0.shape
         z = self.new(tuple(in0.shape))
         dims = (c_int(N), c_int(H), c_int(W), c_int(C))
@@ -278,11 +284,12 @@ class EffDetPlan(RetinaPlan):
             if not self.has_grad(z):
                 return
             gz = self.grad(z)
-            gw = self._zero_bwd_alloc(4)
-            self._step(self.bwd_steps, 'mi355_bifpn_node_wgrad', ptr(gz), ptr(in0), ptr(in1), c_int(int(up1)),
-                       ptr(in2), ptr(gw), *dims)
-            self._fusion_bwd.append((param, n, gw))
-            self._step(self.bwd_steps, '__fusion_bwd__', len(self._fusion_bwd) - 1)
+            if param is not None:
+                gw = self._zero_bwd_alloc(4)
+                self._step(self.bwd_steps, 'mi355_bifpn_node_wgrad', ptr(gz), ptr(in0), ptr(in1), c_int(int(up1)),
+                           ptr(in2), ptr(gw), *dims)
+                self._fusion_bwd.append((param, n, gw))
+                self._step(self.bwd_steps, '__fusion_bwd__', len(self._fusion_bwd) - 1)
             self._axpy(gz, w, 0, self.grad(in0), not self.first_write(in0))
             if up1:
                 self._step(self.bwd_steps, 'mi355_upsample_bwd_axpy', ptr(gz), ptr(w), c_int(1), ptr(self.grad(in1)),
@@ -405,17 +412,21 @@ class EffDetPlan(RetinaPlan):
             p5_in = self.pw_op(rec['p5_down_channel'], p5)
         else:
             p3_in, p4_in, p5_in, p6_in, p7_in = inputs
-        p6_up = self.sep_op(rec['conv6_up'], self.node_op(cell.p6_w1, p6_in, p7_in, True))
-        p5_up = self.sep_op(rec['conv5_up'], self.node_op(cell.p5_w1, p5_in, p6_up, True))
-        p4_up = self.sep_op(rec['conv4_up'], self.node_op(cell.p4_w1, p4_in, p5_up, True))
-        p3_out = self.sep_op(rec['conv3_up'], self.node_op(cell.p3_w1, p3_in, p4_up, True))
+        att = getattr(cell, 'attention', True)                   # False: plain sum, fusion parameters unused
+
+        def fw(name):
+            return getattr(cell, name) if att else None
+        p6_up = self.sep_op(rec['conv6_up'], self.node_op(fw('p6_w1'), p6_in, p7_in, True))
+        p5_up = self.sep_op(rec['conv5_up'], self.node_op(fw('p5_w1'), p5_in, p6_up, True))
+        p4_up = self.sep_op(rec['conv4_up'], self.node_op(fw('p4_w1'), p4_in, p5_up, True))
+        p3_out = self.sep_op(rec['conv3_up'], self.node_op(fw('p3_w1'), p3_in, p4_up, True))
         if rec['first']:
             p4_in = self.pw_op(rec['p4_down_channel_2'], inputs[1])
             p5_in = self.pw_op(rec['p5_down_channel_2'], inputs[2])
-        p4_out = self.sep_op(rec['conv4_down'], self.node_op(cell.p4_w2, p4_in, p4_up, False, self.pool_op(p3_out)))
-        p5_out = self.sep_op(rec['conv5_down'], self.node_op(cell.p5_w2, p5_in, p5_up, False, self.pool_op(p4_out)))
-        p6_out = self.sep_op(rec['conv6_down'], self.node_op(cell.p6_w2, p6_in, p6_up, False, self.pool_op(p5_out)))
-        p7_out = self.sep_op(rec['conv7_down'], self.node_op(cell.p7_w2, p7_in, self.pool_op(p6_out), False))
+        p4_out = self.sep_op(rec['conv4_down'], self.node_op(fw('p4_w2'), p4_in, p4_up, False, self.pool_op(p3_out)))
+        p5_out = self.sep_op(rec['conv5_down'], self.node_op(fw('p5_w2'), p5_in, p5_up, False, self.pool_op(p4_out)))
+        p6_out = self.sep_op(rec['conv6_down'], self.node_op(fw('p6_w2'), p6_in, p6_up, False, self.pool_op(p5_out)))
+        p7_out = self.sep_op(rec['conv7_down'], self.node_op(fw('p7_w2'), p7_in, self.pool_op(p6_out), False))
         return p3_out, p4_out, p5_out, p6_out, p7_out
 
     def _head_fwd(self, rec, out, kout, act, gout, pitch):

@@ -142,8 +142,15 @@ def fusion_weights(w, eps=1e-4):
     return w / (w.sum(dim=0) + eps)
 
 
-def bifpn_cell(p, pre, inputs, first_time):
-    """efficientdet.py:195-267 (`_forward_fast_attention`)."""
+_fusion_weights = fusion_weights
+
+
+def bifpn_cell(p, pre, inputs, first_time, attention=True):
+    """efficientdet.py:195-267 (`_forward_fast_attention`); attention=False: `_forward` (:269-317), the plain
+    sum of the same inputs (D6 / D7, :478), the fusion parameters unused."""
+    def fusion_weights(w):                       # noqa: F811  (shadows the module-level helper in plain mode)
+        return _fusion_weights(w) if attention else torch.ones_like(w)
+
     def cb(x, name):           # 1x1 conv + BN
         return bn(F.conv2d(x, p[pre + name + '.0.conv.weight'], p[pre + name + '.0.conv.bias']), p, pre + name + '.1')
 
@@ -194,7 +201,7 @@ def efficientdet_heads(p, img, compound_coef, num_classes):
     """efficientdet.py:528-539. Returns (classification [B,A,C] probabilities, regression [B,A,4])."""
     feats = backbone(p, img, compound_coef)
     for c in range(FPN_REPEATS[compound_coef]):
-        feats = bifpn_cell(p, 'bifpn.%d.' % c, feats, c == 0)
+        feats = bifpn_cell(p, 'bifpn.%d.' % c, feats, c == 0, attention=compound_coef < 6)
         for l, f in enumerate(feats):
             _tr('cell%d_p%d' % (c, l + 3), f)
     n = BOX_CLASS_REPEATS[compound_coef]

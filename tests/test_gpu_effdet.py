@@ -29,7 +29,7 @@ def _build(tag, golden_dir):
     return g, model, img, ann, sd, coef, nc
 
 
-@pytest.mark.parametrize('tag', ['effdet_d0_128', 'effdet_d2_128x256'])
+@pytest.mark.parametrize('tag', ['effdet_d0_128', 'effdet_d2_128x256', 'effdet_d6_128'])
 def test_effdet_vs_reference_golden(golden_dir, tag):
     g, model, img, ann, sd, coef, nc = _build(tag, golden_dir)
     cls, reg = model(img, return_head=True)

@@ -96,7 +96,7 @@ def test_oracle_state_shapes_helper():
     assert len(s) == 354
 
 
-@pytest.mark.parametrize('tag,coef', [('effdet_d0_128', 0), ('effdet_d2_128x256', 2)])
+@pytest.mark.parametrize('tag,coef', [('effdet_d0_128', 0), ('effdet_d2_128x256', 2), ('effdet_d6_128', 6)])
 def test_efficientdet_state_dict_matches_reference(golden_dir, tag, coef):
     from objectdetection.pytorch_amd.architectures import efficientdet
     g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))

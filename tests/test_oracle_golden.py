@@ -114,7 +114,7 @@ def test_retinanet_end_to_end(golden_dir, tag):
     np.testing.assert_allclose(b.numpy(), g['det_boxes'], rtol=1e-3, atol=1e-2)
 
 
-@pytest.mark.parametrize('tag', ['effdet_d0_128', 'effdet_d2_128x256'])
+@pytest.mark.parametrize('tag', ['effdet_d0_128', 'effdet_d2_128x256', 'effdet_d6_128'])
 def test_efficientdet_end_to_end(golden_dir, tag):
     from oracle import ref_effdet
     g = _load(golden_dir, 'e2e_%s.npz' % tag)

@@ -489,3 +489,5 @@ if __name__ == '__main__':
     if 'effdet' in which:
         gen_e2e_effdet(0, 128, 128, 2, 8, 'effdet_d0_128', 1.0, 0.05)      # configs[3] family
         gen_e2e_effdet(2, 128, 256, 1, 5, 'effdet_d2_128x256', 1.0, 0.05)  # configs[4] family
+    if 'effdet6' in which:
+        gen_e2e_effdet(6, 128, 128, 1, 4, 'effdet_d6_128', 0.73, 0.05)      # plain-sum BiFPN (attention=False)
