@@ -75,6 +75,11 @@ int mi355_bifpn_node_wgrad(const void* gz, const void* in0, const void* in1, int
 /* dst (+)= w[wi] * src  (same shape, n elements) */
 int mi355_axpy_bf16(const void* src, const float* w, int wi, void* dst, int64_t n, int accumulate,
                     void* stream);
+/* Drop-connect of an MBConv skip branch (utils_efficientnet.py:85-94, efficientnet.py:109-113):
+ * dst[n] = src[n] / keep * floor(keep + u[n]) (+ addend[n]); u: device float[N] uniforms in [0, 1), one per image;
+ * per_image = H*W*C elements.  Backward of the branch = the same call on the gradient with addend NULL. */
+int mi355_drop_connect(const void* src, const float* u, float keep, const void* addend, void* dst, int N,
+                       int64_t per_image, void* stream);
 /* dst[N][H/2][W/2][C] (+)= w[wi] * (sum of the 2x2 children of src[N][H][W][C]) */
 int mi355_upsample_bwd_axpy(const void* src, const float* w, int wi, void* dst, int N, int H, int W, int C,
                             int accumulate, void* stream);

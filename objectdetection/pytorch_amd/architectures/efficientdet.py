@@ -197,10 +197,16 @@ class EfficientDet(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.BatchNorm2d) and m.training:
                 raise RuntimeError('train-mode BatchNorm is not on the frozen-BN hot path: call freeze_bn()')
-        key = (img.shape[0], img.shape[2], img.shape[3], img.device.index)
+        # drop-connect runs while the MBConv blocks are in train mode (efficientnet.py:109-113 `training=self.training`)
+        gp = self.backbone_net.model._global_params
+        dc = bool(getattr(gp, 'drop_connect_rate', None)) and any(b.training for b in self.backbone_net.model._blocks)
+        key = (img.shape[0], img.shape[2], img.shape[3], img.device.index, dc)
         from .retinanet import _cached_plan
-        return _cached_plan(self, key, lambda: engine_effdet.EffDetPlan(self, img.shape[0], img.shape[2], img.shape[3],
-                                                                        img.device))
+
+        def build():
+            self._plan_drop_connect = dc
+            return engine_effdet.EffDetPlan(self, img.shape[0], img.shape[2], img.shape[3], img.device)
+        return _cached_plan(self, key, build)
 
     def forward(self, images, annotations=None, return_loss=True, return_head=False):
         """efficientdet.py:528-576 (`return_head` is an extension mirroring RetinaNet's: returns

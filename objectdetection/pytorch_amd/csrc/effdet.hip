@@ -1042,6 +1042,39 @@ extern "C" int mi355_axpy_bf16(const void* src, const float* w, int wi, void* ds
     return check_launch("axpy_kernel");
 }
 
+// drop-connect (utils_efficientnet.py:85-94): dst = src / keep * floor(keep + u[n]) (+ addend), one uniform per image
+__global__ void drop_connect_kernel(const unsigned short* __restrict__ src, const float* __restrict__ u, float keep,
+                                    const unsigned short* __restrict__ addend, unsigned short* __restrict__ dst,
+                                    long long per_image8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_image8) return;
+    const int n = blockIdx.y;
+    const float b = floorf(keep + u[n]);
+    const long long t = (long long)n * per_image8 + i;
+    float v[8], o[8];
+    load8(src + t * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = v[e] / keep * b;
+    if (addend) {
+        float a[8];
+        load8(addend + t * 8, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += a[e];
+    }
+    store8(dst + t * 8, o);
+}
+
+extern "C" int mi355_drop_connect(const void* src, const float* u, float keep, const void* addend, void* dst, int N,
+                                  int64_t per_image, void* stream) {
+    MI355_REQUIRE(src && u && dst && N > 0 && N <= 65535 && per_image > 0 && per_image % 8 == 0,
+                  "drop_connect: bad args (per_image must be a multiple of 8)");
+    MI355_REQUIRE(keep > 0.0f && keep <= 1.0f, "drop_connect: keep probability %g outside (0, 1]", (double)keep);
+    hipLaunchKernelGGL(drop_connect_kernel, dim3(blocks_for(per_image / 8), (unsigned)N), dim3(256), 0,
+                       (hipStream_t)stream, (const unsigned short*)src, u, keep, (const unsigned short*)addend,
+                       (unsigned short*)dst, (long long)(per_image / 8));
+    return check_launch("drop_connect_kernel");
+}
+
 __global__ void upsample_bwd_axpy_kernel(const unsigned short* __restrict__ src, const float* __restrict__ w, int wi,
                                          unsigned short* __restrict__ dst, int N, int H, int W, int C, int accumulate) {
     const int c8n = C >> 3, P = H >> 1, Q = W >> 1;

@@ -301,6 +301,30 @@ class EffDetPlan(RetinaPlan):
         self.tape.append(bwd)
         return z
 
+    def drop_connect_op(self, branch, skip, keep):
+        """out = branch / keep * floor(keep + u[n]) + skip (efficientnet.py:109-113); u: this block's row of the
+        per-step uniform table."""
+        row = self._dc_rows
+        self._dc_rows += 1
+        N = branch.shape[0]
+        per = branch.numel() // N
+        u = self.dc_u[row]
+        out = self.new(tuple(branch.shape))
+        self._step(self.fwd_steps, 'mi355_drop_connect', ptr(branch), ptr(u), c_f32(keep), ptr(skip), ptr(out),
+                   c_int(N), c_i64(per))
+
+        def bwd():
+            if not self.has_grad(out):
+                return
+            dy = self.grad(out)
+            self._axpy(dy, None, 0, self.grad(skip), not self.first_write(skip))
+            gb = self.grad(branch)
+            assert self.first_write(branch)
+            self._step(self.bwd_steps, 'mi355_drop_connect', ptr(dy), ptr(u), c_f32(keep), c_vp(0), ptr(gb),
+                       c_int(N), c_i64(per))
+        self.tape.append(bwd)
+        return out
+
     def _swish_tmp(self, n):
         """One shared scratch tensor (launches are stream-ordered) for materialised swish(z)."""
         if getattr(self, '_swish_buf', None) is None or self._swish_buf.numel() < n:
@@ -346,6 +370,13 @@ class EffDetPlan(RetinaPlan):
         cur_sw = True
         feats, last = [], None
         nblk = len(self.blocks)
+        eff_gp = self.model.backbone_net.model._global_params
+        # drop-connect (utils_efficientnet.py:85-94) is part of the step while the MBConv blocks are in train mode
+        self.drop_connect = bool(getattr(self.model, '_plan_drop_connect', False))
+        self._dc_rows = 0
+        ndc = sum(1 for r in self.blocks if r['skip'])
+        self.dc_u = torch.zeros((max(ndc, 1), B), dtype=torch.float32, device=self.dev)
+        self.dc_inject = None                                  # tests: a fixed [rows, B] table of uniforms
         for i, rec in enumerate(self.blocks):
             inp = cur
             if rec['expand'] is not None:
@@ -355,7 +386,12 @@ class EffDetPlan(RetinaPlan):
                 dw_in, dw_sw = inp, cur_sw
             z1 = self.dw_op(rec['dw'], dw_in, dw_sw)
             u = self.se_op(rec['se'], z1)
-            cur = self.pw_op(rec['project'], u, addend=inp if rec['skip'] else None)
+            rate = getattr(eff_gp, 'drop_connect_rate', None)
+            rate = rate * float(i) / nblk if rate else 0.0                 # efficientdet.py:421-423
+            if rec['skip'] and self.drop_connect and rate:
+                cur = self.drop_connect_op(self.pw_op(rec['project'], u), inp, 1.0 - rate)
+            else:
+                cur = self.pw_op(rec['project'], u, addend=inp if rec['skip'] else None)
             pre = 'backbone_net.model._blocks.%d' % i
             self.dbg[pre + '.z1'], self.dbg[pre + '.u'], self.dbg['block%d' % i] = z1, u, cur
             if rec['expand'] is not None:
@@ -562,6 +598,11 @@ class EffDetPlan(RetinaPlan):
 
     def run_heads(self, img):
         self._zf.zero_()
+        if self.drop_connect and self._dc_rows:
+            if self.dc_inject is not None:
+                self.dc_u[:self.dc_inject.shape[0]].copy_(self.dc_inject)
+            else:
+                self.dc_u.uniform_()                            # device RNG, one uniform per (block, image)
         super(EffDetPlan, self).run_heads(img)
 
     def _arena_for_backward(self):

@@ -96,8 +96,16 @@ def bn(x, p, pre):
                         p[pre + '.bias'], False, 0.0, BN_EPS)
 
 
-def mbconv(x, p, pre, k, s, e, cin, cout):
-    """efficientnet.py:80-115 (drop-connect off)."""
+def drop_connect(x, rate, u):
+    """utils_efficientnet.py:85-94 with the uniforms `u` [B] handed in (the reference draws them with torch.rand)."""
+    keep = 1 - rate
+    binary = torch.floor(keep + u.reshape(-1, 1, 1, 1).to(x.dtype))
+    return x / keep * binary
+
+
+def mbconv(x, p, pre, k, s, e, cin, cout, dc=None):
+    """efficientnet.py:80-115; dc = (rate, uniforms [B]) for the train-mode drop-connect of the skip branch
+    (:109-113), None = off (eval mode / rate 0)."""
     inp = x
     if e != 1:
         x = swish(_tr(pre + '.z0', bn(conv_same(x, p[pre + '._expand_conv.conv.weight']), p, pre + '._bn0')))
@@ -108,18 +116,28 @@ def mbconv(x, p, pre, k, s, e, cin, cout):
     x = _tr(pre + '.u', torch.sigmoid(sq) * x)
     x = bn(conv_same(x, p[pre + '._project_conv.conv.weight']), p, pre + '._bn2')
     if s == 1 and cin == cout:
+        if dc is not None and dc[0]:
+            x = drop_connect(x, dc[0], dc[1])
         x = x + inp
     return x
 
 
-def backbone(p, img, compound_coef):
-    """efficientdet.py:411-433: returns (p3, p4, p5) = feature_maps[1:] minus P2 (:533)."""
+def backbone(p, img, compound_coef, dc_u=None, dc_rate=0.2):
+    """efficientdet.py:411-433: returns (p3, p4, p5) = feature_maps[1:] minus P2 (:533).  dc_u: [rows, B] uniforms,
+    one row per block with a skip connection in block order (train mode: rate = dc_rate * idx / len(blocks), :421-423)."""
     _, blocks = block_table(compound_coef)
     pre = 'backbone_net.model.'
     x = swish(_tr('stem_z', bn(conv_same(img, p[pre + '_conv_stem.conv.weight'], None, 2), p, pre + '_bn0')))
     feats, last = [], None
+    row = 0
     for i, (k, s, e, ci, co) in enumerate(blocks):
-        x = _tr('block%d' % i, mbconv(x, p, pre + '_blocks.%d' % i, k, s, e, ci, co))
+        dc = None
+        if dc_u is not None and s == 1 and ci == co:
+            rate = dc_rate * float(i) / len(blocks)
+            if rate:                             # block 0: rate 0 -> no draw (efficientnet.py:110)
+                dc = (rate, dc_u[row])
+                row += 1
+        x = _tr('block%d' % i, mbconv(x, p, pre + '_blocks.%d' % i, k, s, e, ci, co, dc))
         if s == 2:
             feats.append(last)
         elif i == len(blocks) - 1:
@@ -197,9 +215,9 @@ def head(p, pre, feats, nlayers, last_dim):
     return torch.cat(outs, dim=1)
 
 
-def efficientdet_heads(p, img, compound_coef, num_classes):
+def efficientdet_heads(p, img, compound_coef, num_classes, dc_u=None):
     """efficientdet.py:528-539. Returns (classification [B,A,C] probabilities, regression [B,A,4])."""
-    feats = backbone(p, img, compound_coef)
+    feats = backbone(p, img, compound_coef, dc_u)
     for c in range(FPN_REPEATS[compound_coef]):
         feats = bifpn_cell(p, 'bifpn.%d.' % c, feats, c == 0, attention=compound_coef < 6)
         for l, f in enumerate(feats):

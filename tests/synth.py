@@ -108,3 +108,11 @@ def synth_head_outputs(batch, num_anchors, num_classes, seed=3, hot_fraction=0.0
     cls = (1.0 / (1.0 + np.exp(-logits))).astype(np.float32)
     reg = (0.5 * rng.standard_normal((batch, num_anchors, 4))).astype(np.float32)
     return cls, reg
+
+
+def disable_drop_connect(model):
+    """EfficientNet's drop-connect rate lives in the backbone's global params (utils_efficientnet.py GlobalParams);
+    clearing it is how the deterministic (eval-mode) goldens' path is selected on a model in train mode."""
+    eff = model.backbone_net.model
+    eff._global_params = eff._global_params._replace(drop_connect_rate=None)
+    return model

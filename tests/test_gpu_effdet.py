@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda', 0)
 
 
-def _build(tag, golden_dir):
+def _build(tag, golden_dir, drop_connect=False):
     from objectdetection.pytorch_amd.architectures import efficientdet
     g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
     coef, (H, W), B, nc = int(g['coef']), g['hw'], int(g['batch']), int(g['num_classes'])
@@ -24,6 +24,8 @@ def _build(tag, golden_dir):
     model = model.to(DEV)
     model.train()
     model.freeze_bn()
+    if not drop_connect:                  # goldens made with the reference in eval mode: no drop-connect draws
+        synth.disable_drop_connect(model)
     img = torch.from_numpy(synth.synth_images(B, int(H), int(W), seed=1)).to(DEV)
     ann = torch.from_numpy(synth.synth_annotations(B, int(H), int(W), 6, 8, nc, seed=2)).to(DEV)
     return g, model, img, ann, sd, coef, nc
@@ -87,3 +89,44 @@ def test_effdet_decode_tail(golden_dir):
     np.testing.assert_allclose(boxes.cpu().numpy(), bo.numpy(), rtol=1e-4, atol=1e-3)
     n_ref = g['det_scores'].shape[0]
     assert abs(len(so) - n_ref) <= max(3, 0.2 * n_ref)
+
+
+def test_drop_connect_vs_reference_golden(golden_dir):
+    """Train mode as the reference trains (train.py:273-286): drop-connect on the MBConv skip branches
+    (utils_efficientnet.py:85-94), fed with the uniforms the reference drew when the golden was made."""
+    g, model, img, ann, sd, coef, nc = _build('effdet_d0_dropconnect_128', golden_dir, drop_connect=True)
+    plan = model._plan(img)
+    assert plan.drop_connect and plan._dc_rows == g['dc_u'].shape[0]
+    plan.dc_inject = torch.from_numpy(g['dc_u']).to(DEV)
+    cl, rl = model(img, ann)
+    np.testing.assert_allclose(cl.item(), g['cls_loss'].item(), rtol=3e-2)
+    np.testing.assert_allclose(rl.item(), g['reg_loss'].item(), rtol=3e-2)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = dict((k, p.grad) for k, p in model.named_parameters())
+    gn = np.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values()))
+    np.testing.assert_allclose(gn, float(g['grad_global_norm']), rtol=6e-2)
+    for key in g.files:
+        if key.startswith('grad/') and key.endswith('/val'):
+            name = key[5:-4]
+            got = grads[name].reshape(-1)[torch.from_numpy(g['grad/%s/idx' % name]).to(DEV)].cpu().numpy()
+            ref = g[key]
+            if np.linalg.norm(ref) < 1e-5 * gn:
+                assert np.abs(got - ref).max() <= 1e-5 * gn, name
+                continue
+            cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+            assert cos > 0.95, (name, cos)
+    # all branches kept (u = 1 - tiny): out = branch / keep + skip; all dropped (u = 0, rate > 0): out = skip
+    plan.dc_inject = torch.full_like(plan.dc_inject, 0.999999)
+    kept = [x.item() for x in model(img, ann)]
+    plan.dc_inject = torch.zeros_like(plan.dc_inject)
+    dropped = [x.item() for x in model(img, ann)]
+    assert np.isfinite(kept + dropped).all() and kept != dropped
+    # the draws of the product path come from the device generator: two steps differ, eval mode has no draws
+    plan.dc_inject = None
+    a, b = [x.item() for x in model(img, ann)], [x.item() for x in model(img, ann)]
+    assert a != b
+    model.eval()
+    assert not model._plan(img).drop_connect
+    e1, e2 = [x.item() for x in model(img, ann)], [x.item() for x in model(img, ann)]
+    assert e1 == e2

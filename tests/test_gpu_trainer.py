@@ -130,7 +130,7 @@ def test_graph_replay_matches_eager(arch):
         m = m.to(dev)
         m.train()
         m.freeze_bn()
-        return m
+        return synth.disable_drop_connect(m)       # eager and replayed steps must draw nothing to be comparable
     batches = [(torch.from_numpy(synth.synth_images(B, H, W, seed=10 + i)).to(dev),
                 torch.from_numpy(synth.synth_annotations(B, H, W, 6, 8 + 2 * (i % 2), nc, seed=20 + i)).to(dev))
                for i in range(4)]

@@ -147,6 +147,35 @@ def test_efficientdet_end_to_end(golden_dir, tag):
     np.testing.assert_allclose(b.numpy(), g['det_boxes'], rtol=1e-3, atol=1e-2)
 
 
+def test_efficientdet_drop_connect(golden_dir):
+    """Train-mode MBConv skip branches (efficientnet.py:109-113, utils_efficientnet.py:85-94) with the reference's
+    own draws: the oracle restates `x / keep * floor(keep + u)` per image."""
+    from oracle import ref_effdet
+    g = _load(golden_dir, 'e2e_effdet_d0_dropconnect_128.npz')
+    coef, (H, W), B, nc = int(g['coef']), g['hw'], int(g['batch']), int(g['num_classes'])
+    shapes = {str(k): tuple(int(v) for v in str(s).split(',') if v) for k, s in zip(g['state_keys'], g['state_shapes'])}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=float(g['gain']), head_std=float(g['head_std']))
+    p = {k: torch.from_numpy(v).requires_grad_(v.dtype == np.float32 and 'running' not in k) for k, v in sd.items()}
+    img = torch.from_numpy(synth.synth_images(B, int(H), int(W), seed=1))
+    ann = torch.from_numpy(synth.synth_annotations(B, int(H), int(W), 6, 8, nc, seed=2))
+    cls, reg = ref_effdet.efficientdet_heads(p, img, coef, nc, dc_u=torch.from_numpy(g['dc_u']))
+    anchors = torch.from_numpy(ref_cpu.anchors_for_image(int(H), int(W), **ref_effdet.ANCHOR_CFG))
+    cl, rl = ref_cpu.focal_loss(cls, reg, anchors, ann)
+    np.testing.assert_allclose(cl.detach().numpy(), g['cls_loss'], rtol=1e-5)
+    np.testing.assert_allclose(rl.detach().numpy(), g['reg_loss'], rtol=1e-5)
+    (cl.mean() + rl.mean()).backward()
+    for key in g.files:
+        if key.startswith('grad/') and key.endswith('/val'):
+            name = key[5:-4]
+            got = p[name].grad.reshape(-1)[torch.from_numpy(g['grad/%s/idx' % name])].numpy()
+            scale = float(g['grad/%s/norm' % name]) / np.sqrt(p[name].numel())
+            np.testing.assert_allclose(got, g[key], rtol=2e-3, atol=2e-3 * scale, err_msg=name)
+    # without the draws the losses differ: the golden really exercises the dropped branches
+    cls0, reg0 = ref_effdet.efficientdet_heads(p, img, coef, nc)
+    cl0, _ = ref_cpu.focal_loss(cls0, reg0, anchors, ann)
+    assert abs(cl0.item() - g['cls_loss'].item()) > 1e-4 * g['cls_loss'].item()
+
+
 def test_input_side_normalizer_collater(golden_dir):
     """a-0 / f-2: the numpy restatement of load scaling + Normalizer + collater against the reference's own
     output (datasettool/dataloader.py:92, :905-924, :655-691), bit for bit."""

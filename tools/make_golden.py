@@ -468,6 +468,56 @@ def gen_e2e_effdet(coef, H, W, B, num_classes, tag, gain, head_std):
           'cls range', float(cls.min()), float(cls.max()))
 
 
+def gen_effdet_drop_connect(coef, H, W, B, num_classes, tag, gain, head_std):
+    """EfficientDet in the state the reference trains it in (train.py:273-286: `.train()` then `freeze_bn()`): the
+    MBConv blocks are in train mode, so drop-connect (utils_efficientnet.py:85-94) draws one torch.rand per image
+    and skip block.  The draws are recorded so that the HIP path and the oracle can be fed the same uniforms."""
+    from architectures import efficientdet as ref_eff
+    torch.manual_seed(0)
+    model = ref_eff.build_efficientdet('efficientdet-d%d' % coef, num_classes=num_classes)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=gain, head_std=head_std)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.train()
+    model.freeze_bn()
+    img_t = torch.from_numpy(synth.synth_images(B, H, W, seed=1))
+    ann_t = torch.from_numpy(synth.synth_annotations(B, H, W, num_real=6, pad_to=8, num_classes=num_classes, seed=2))
+    draws, real_rand = [], torch.rand
+
+    def recording_rand(*a, **k):
+        t = real_rand(*a, **k)
+        draws.append(t.reshape(-1).clone())
+        return t
+    torch.manual_seed(4321)
+    torch.rand = recording_rand
+    try:
+        cl, rl = model(img_t, ann_t)
+    finally:
+        torch.rand = real_rand
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+    u = torch.stack(draws).numpy()
+    d = dict(cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(), coef=np.array(coef), hw=np.array([H, W]),
+             batch=np.array(B), num_classes=np.array(num_classes), gain=np.array(gain), head_std=np.array(head_std),
+             dc_u=u)
+    for k in EFF_GRAD_KEYS:
+        if k in grads:
+            g = grads[k]
+            d['grad/' + k + '/norm'] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            flat = g.reshape(-1)
+            sel = np.linspace(0, flat.size - 1, min(flat.size, 512)).astype(np.int64)
+            d['grad/' + k + '/idx'] = sel
+            d['grad/' + k + '/val'] = flat[sel]
+    d['grad_global_norm'] = np.array(np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in grads.values())))
+    d['state_keys'] = np.array(list(shapes.keys()))
+    d['state_shapes'] = np.array([','.join(map(str, shapes[k])) for k in shapes])
+    np.savez_compressed(os.path.join(OUT, 'e2e_%s.npz' % tag), **d)
+    keep = 1 - 0.2 * np.arange(16) / 16
+    print('e2e', tag, 'cls', cl.item(), 'reg', rl.item(), 'draws', u.shape, 'dropped branches',
+          int((u < 0.2).sum()), 'gnorm', d['grad_global_norm'])
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['anchors', 'loss', 'decode', 'e2e', 'effdet', 'variants', 'postprocess', 'input']
     if 'anchors' in which:
@@ -489,5 +539,7 @@ if __name__ == '__main__':
     if 'effdet' in which:
         gen_e2e_effdet(0, 128, 128, 2, 8, 'effdet_d0_128', 1.0, 0.05)      # configs[3] family
         gen_e2e_effdet(2, 128, 256, 1, 5, 'effdet_d2_128x256', 1.0, 0.05)  # configs[4] family
+    if 'effdet_dc' in which:
+        gen_effdet_drop_connect(0, 128, 128, 4, 8, 'effdet_d0_dropconnect_128', 1.0, 0.05)
     if 'effdet6' in which:
         gen_e2e_effdet(6, 128, 128, 1, 4, 'effdet_d6_128', 0.73, 0.05)      # plain-sum BiFPN (attention=False)
