@@ -788,7 +788,7 @@ class RetinaPlan(object):
         arena = self.begin_backward(g_cls, g_reg)
         st = self._stream()
         if type(self)._build_backward is RetinaPlan._build_backward and self.pgrad_specs:
-            for seg in self.backward_segments():       # parameter-gradient tables ride the side stream
+            for seg in self.backward_segments(int(os.environ.get('MI355_SEG_MB', '32')) << 20):   # tables ride the side stream
                 self.run_backward_segment(seg)
             self.join_side()
         else:
