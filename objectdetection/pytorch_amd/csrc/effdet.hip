@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_s1_kernel(const unsigned short
 // fetched ONCE (the direct kernels fetch every input K*K times through L1/L2), kept as [chunk][pixel] planes of
 // 16-B cells (consecutive lanes = consecutive cells: conflict-free ds_read_b128), the taps' weights sit in
 // LDS too, and the outputs go back through LDS so that a pixel's NC8 chunks are stored contiguously.
-constexpr int DT_TH = 8, DT_TW = 32;
+constexpr int DT_TH = 8, DT_TW = 32, DT_OS = DT_TH * DT_TW + 1;
 template <int K, bool FLIP, bool INSW = false>
 __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* __restrict__ in, const float* __restrict__ w_t,
                                                          const float* __restrict__ bias, unsigned short* __restrict__ out,
@@ -190,15 +190,17 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* _
                 acc[4] += bf16_to_f32((unsigned short)v[4]) * w1.x;  acc[5] += bf16_to_f32((unsigned short)v[5]) * w1.y;
                 acc[6] += bf16_to_f32((unsigned short)v[6]) * w1.z;  acc[7] += bf16_to_f32((unsigned short)v[7]) * w1.w;
             }
+        // staging planes [chunk][pixel] (DT_OS = 257 cells apart): consecutive lanes write consecutive cells (a
+        // [pixel][chunk] layout puts lanes 64-128 B apart: 16- to 32-way bank conflicts on every store)
         if (FLIP) {                                        // keep fp32 until the swish' / accumulate epilogue
             float* of = reinterpret_cast<float*>(ot);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) of[(tid * nc8 + ch) * 8 + e] = acc[e];
+            for (int e = 0; e < 8; ++e) of[(ch * DT_OS + tid) * 8 + e] = acc[e];
         } else {
             s8v o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(acc[e]);
-            ot[tid * nc8 + ch] = o;
+            ot[ch * DT_OS + tid] = o;
         }
     }
     __syncthreads();
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* _
         if (p >= H || q >= W) continue;
         const long long off = (((long long)n * H + p) * W + q) * C + (c8b + ch) * 8;
         if (FLIP) {
-            const float* of = reinterpret_cast<const float*>(ot) + (long long)i * 8;
+            const float* of = reinterpret_cast<const float*>(ot) + (long long)(ch * DT_OS + px) * 8;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = of[e];
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* _
             }
             store8(out + off, v);
         } else {
-            *reinterpret_cast<s8v*>(out + off) = ot[i];
+            *reinterpret_cast<s8v*>(out + off) = ot[ch * DT_OS + px];
         }
     }
 }
@@ -238,7 +240,7 @@ static int launch_dw_tile(const void* in, const float* w_t, const float* bias, v
     const int c8n = C / 8;
     const int nc8 = c8n % 4 == 0 ? 4 : (c8n % 2 == 0 ? 2 : 1);
     constexpr int NPX = (DT_TH + K - 1) * (DT_TW + K - 1);
-    const size_t lds = (size_t)nc8 * NPX * 16 + (size_t)K * K * nc8 * 32 + (size_t)256 * nc8 * (FLIP ? 32 : 16);
+    const size_t lds = (size_t)nc8 * NPX * 16 + (size_t)K * K * nc8 * 32 + (size_t)DT_OS * nc8 * (FLIP ? 32 : 16);
     const dim3 grid((unsigned)((W + DT_TW - 1) / DT_TW), (unsigned)((H + DT_TH - 1) / DT_TH), (unsigned)(N * (c8n / nc8)));
     static bool attr = false;
     if (!attr) {
