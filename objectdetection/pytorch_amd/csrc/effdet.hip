@@ -12,9 +12,21 @@ using namespace mi355;
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float swishf(float x) { return x * sigmoidf_(x); }
-__device__ __forceinline__ float dswishf(float x) {          // utils_efficientnet.py:46-49
+__device__ __forceinline__ float swishf_exact(float x) { return x * sigmoidf_(x); }          // fp32 SE vectors
+__device__ __forceinline__ float dswishf_exact(float x) {    // utils_efficientnet.py:46-49
     const float s = sigmoidf_(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+// Activation maps are bf16: v_exp_f32 + v_rcp_f32 (1-2 ulp in fp32, far below the bf16 rounding that follows)
+// instead of the accurate expf + IEEE division (~3x the instructions); every kernel that turns a stored
+// pre-activation z into swish(z) uses this one function, so the forward, the weight gradient and a materialised
+// copy see the same bf16 values.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float swishf(float x) { return x * fast_sigmoid(x); }
+__device__ __forceinline__ float dswishf(float x) {
+    const float s = fast_sigmoid(x);
     return s * (1.0f + x * (1.0f - s));
 }
 __device__ __forceinline__ void load8(const unsigned short* p, float v[8]) {
@@ -771,7 +783,7 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pa
         if (lane == 0) {
             t += b1[j];
             rpre[(long long)n * Cse + j] = t;
-            s_r[j] = swishf(t);
+            s_r[j] = swishf_exact(t);
         }
     }
     __syncthreads();
@@ -817,7 +829,7 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict_
         s_de[c] = de;
         if (sl_i == 0) atomicAdd(db2 + c, de);
     }
-    for (int j = tid; j < Cse; j += 256) s_r[j] = swishf(rpre[(long long)n * Cse + j]);
+    for (int j = tid; j < Cse; j += 256) s_r[j] = swishf_exact(rpre[(long long)n * Cse + j]);
     __syncthreads();
     const int tot2 = C * Cse;
     const int lo2 = (int)((long long)tot2 * sl_i / sl_n), hi2 = (int)((long long)tot2 * (sl_i + 1) / sl_n);
@@ -849,7 +861,7 @@ __global__ __launch_bounds__(256) void se_fc_bwd_kernel(const float* __restrict_
         if (tid < 16 && j0 + tid < Cse) {
             const int j = j0 + tid;
             const float v = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
-            const float d = v * dswishf(rpre[(long long)n * Cse + j]);
+            const float d = v * dswishf_exact(rpre[(long long)n * Cse + j]);
             s_dr[j] = d;
             if (sl_i == 0) atomicAdd(db1 + j, d);
         }
