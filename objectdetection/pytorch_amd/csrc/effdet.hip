@@ -204,16 +204,12 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* _
             }
         // staging planes [chunk][pixel] (DT_OS = 257 cells apart): consecutive lanes write consecutive cells (a
         // [pixel][chunk] layout puts lanes 64-128 B apart: 16- to 32-way bank conflicts on every store)
-        if (FLIP) {                                        // keep fp32 until the swish' / accumulate epilogue
-            float* of = reinterpret_cast<float*>(ot);
+        // (the data gradient stages bf16 too: fp32 cells doubled the LDS footprint to 56 KiB = 2 blocks per CU for
+        //  a memory-bound kernel; the swish' / accumulate epilogue then rounds once more, 2^-9 relative)
+        s8v o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) of[(ch * DT_OS + tid) * 8 + e] = acc[e];
-        } else {
-            s8v o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(acc[e]);
-            ot[ch * DT_OS + tid] = o;
-        }
+        for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(acc[e]);
+        ot[ch * DT_OS + tid] = o;
     }
     __syncthreads();
     // ---- outputs: piece i = (pixel, chunk), a pixel's chunks contiguous in memory
@@ -223,10 +219,10 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* _
         if (p >= H || q >= W) continue;
         const long long off = (((long long)n * H + p) * W + q) * C + (c8b + ch) * 8;
         if (FLIP) {
-            const float* of = reinterpret_cast<const float*>(ot) + (long long)(ch * DT_OS + px) * 8;
+            const s8v sv = ot[ch * DT_OS + px];
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = of[e];
+            for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((unsigned short)sv[e]);
             if (zin) {
                 float z[8];
                 load8(zin + off, z);
@@ -252,7 +248,7 @@ static int launch_dw_tile(const void* in, const float* w_t, const float* bias, v
     const int c8n = C / 8;
     const int nc8 = c8n % 4 == 0 ? 4 : (c8n % 2 == 0 ? 2 : 1);
     constexpr int NPX = (DT_TH + K - 1) * (DT_TW + K - 1);
-    const size_t lds = (size_t)nc8 * NPX * 16 + (size_t)K * K * nc8 * 32 + (size_t)DT_OS * nc8 * (FLIP ? 32 : 16);
+    const size_t lds = (size_t)nc8 * NPX * 16 + (size_t)K * K * nc8 * 32 + (size_t)DT_OS * nc8 * 16;
     const dim3 grid((unsigned)((W + DT_TW - 1) / DT_TW), (unsigned)((H + DT_TH - 1) / DT_TH), (unsigned)(N * (c8n / nc8)));
     static bool attr = false;
     if (!attr) {
