@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* _
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     s8v* tile = reinterpret_cast<s8v*>(smem);                              // [nc8][NPX]
     float* wl = reinterpret_cast<float*>(smem + (size_t)nc8 * NPX * 16);     // [K*K][nc8*8]
-    s8v* ot = reinterpret_cast<s8v*>(smem + (size_t)nc8 * NPX * 16 + (size_t)K * K * nc8 * 32);   // [256][nc8]
+    s8v* ot = reinterpret_cast<s8v*>(smem);                                // [nc8][DT_OS] output staging, aliases `tile`
     const int tid = threadIdx.x;
     const int q0 = blockIdx.x * DT_TW, p0 = blockIdx.y * DT_TH;
     const int groups = (C >> 3) / nc8;
@@ -186,7 +186,10 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* _
     }
     __syncthreads();
     const int ty = tid >> 5, tx = tid & 31;
-    for (int ch = 0; ch < nc8; ++ch) {
+    s8v res[4];                                            // nc8 <= 4 chunks, results held until the tile is dead
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        if (ch >= nc8) break;
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[(c8b + ch) * 8 + e] : 0.0f;
@@ -206,11 +209,14 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* _
         // [pixel][chunk] layout puts lanes 64-128 B apart: 16- to 32-way bank conflicts on every store)
         // (the data gradient stages bf16 too: fp32 cells doubled the LDS footprint to 56 KiB = 2 blocks per CU for
         //  a memory-bound kernel; the swish' / accumulate epilogue then rounds once more, 2^-9 relative)
-        s8v o;
+        //  The staging planes reuse the input tile's LDS (24-29 KiB per block in all: 5-6 blocks per CU).
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(acc[e]);
-        ot[ch * DT_OS + tid] = o;
+        for (int e = 0; e < 8; ++e) res[ch][e] = (short)f32_to_bf16_rn(acc[e]);
     }
+    __syncthreads();                                       // every lane has finished reading the input tile
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+        if (ch < nc8) ot[ch * DT_OS + tid] = res[ch];
     __syncthreads();
     // ---- outputs: piece i = (pixel, chunk), a pixel's chunks contiguous in memory
     for (int i = tid; i < 256 * nc8; i += 256) {
@@ -248,7 +254,8 @@ static int launch_dw_tile(const void* in, const float* w_t, const float* bias, v
     const int c8n = C / 8;
     const int nc8 = c8n % 4 == 0 ? 4 : (c8n % 2 == 0 ? 2 : 1);
     constexpr int NPX = (DT_TH + K - 1) * (DT_TW + K - 1);
-    const size_t lds = (size_t)nc8 * NPX * 16 + (size_t)K * K * nc8 * 32 + (size_t)DT_OS * nc8 * 16;
+    static_assert(NPX >= DT_OS, "output staging must fit in the input tile");
+    const size_t lds = (size_t)nc8 * NPX * 16 + (size_t)K * K * nc8 * 32;
     const dim3 grid((unsigned)((W + DT_TW - 1) / DT_TW), (unsigned)((H + DT_TH - 1) / DT_TH), (unsigned)(N * (c8n / nc8)));
     static bool attr = false;
     if (!attr) {
