@@ -346,6 +346,81 @@ __global__ void dwconv_dgrad_kernel(const unsigned short* __restrict__ dy, const
     store8(dx + t * 8, acc);
 }
 
+// Stride-2 data gradient: a thread owns the 2 x 2 input block (2h', 2w') of one 8-channel chunk.  The block lies
+// under at most CN x CN output cells (CN = (K + 1) / 2 + 1): each (dy cell, tap) pair is visited once, with the tap
+// index a = h + pad_t - 2p known from the cell (the per-pixel kernel walks all K x K taps with a modulo test each).
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(
+    const unsigned short* __restrict__ dy, const float* __restrict__ w_t, unsigned short* __restrict__ dx,
+    const unsigned short* __restrict__ zin, int N, int H, int W, int C, int pad_t, int pad_l, int P, int Q,
+    int accumulate) {
+    constexpr int CN = (K + 1) / 2 + 1;
+    const int c8n = C >> 3, H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * H2 * W2 * c8n) return;
+    const int c8 = (int)(t % c8n);
+    long long r = t / c8n;
+    const int w2 = (int)(r % W2);  r /= W2;
+    const int h2 = (int)(r % H2);
+    const int n = (int)(r / H2);
+    float acc[2][2][8];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) (&acc[0][0][0])[i] = 0.0f;
+    // first output cell that can reach input row 2h2 (+1): 2p - pad_t + a = h, a <= K-1  ->  p >= (h + pad_t - K + 1) / 2
+    const int hb = 2 * h2 + pad_t, wb = 2 * w2 + pad_l;
+    const int p_lo = (hb - K + 2) >> 1, q_lo = (wb - K + 2) >> 1;            // ceil((hb - K + 1) / 2), may be < 0
+    const float* wc = w_t + c8 * 8;
+#pragma unroll
+    for (int i = 0; i < CN; ++i) {
+        const int p = p_lo + i;
+        if (p < 0 || p >= P) continue;
+#pragma unroll
+        for (int j = 0; j < CN; ++j) {
+            const int q = q_lo + j;
+            if (q < 0 || q >= Q) continue;
+            float g[8];
+            load8(dy + (((long long)n * P + p) * Q + q) * C + c8 * 8, g);
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh) {
+                const int a = hb + dh - 2 * p;
+                if (a < 0 || a >= K) continue;
+#pragma unroll
+                for (int dw = 0; dw < 2; ++dw) {
+                    const int b = wb + dw - 2 * q;
+                    if (b < 0 || b >= K) continue;
+                    const float4 w0 = *reinterpret_cast<const float4*>(wc + (a * K + b) * C);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wc + (a * K + b) * C + 4);
+                    float* o = acc[dh][dw];
+                    o[0] += g[0] * w0.x; o[1] += g[1] * w0.y; o[2] += g[2] * w0.z; o[3] += g[3] * w0.w;
+                    o[4] += g[4] * w1.x; o[5] += g[5] * w1.y; o[6] += g[6] * w1.z; o[7] += g[7] * w1.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < 2; ++dw) {
+            const int h = 2 * h2 + dh, w = 2 * w2 + dw;
+            if (h >= H || w >= W) continue;
+            const long long o = ((((long long)n * H + h) * W + w) * c8n + c8) * 8;
+            float* v = acc[dh][dw];
+            if (zin) {
+                float z[8];
+                load8(zin + o, z);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dswishf(z[e]);
+            }
+            if (accumulate) {
+                float old[8];
+                load8(dx + o, old);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += old[e];
+            }
+            store8(dx + o, v);
+        }
+}
+
 extern "C" int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, const void* zin, int N, int H,
                                   int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
                                   int accumulate, void* stream) {
@@ -353,6 +428,18 @@ extern "C" int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, co
     if (stride == 1 && (k == 3 || k == 5) && P == H && Q == W && W >= 16 && H >= 8 && pad_t == (k - 1) / 2 && pad_l == (k - 1) / 2)
         return k == 3 ? launch_dw_tile<3, true>(dy, w_t, nullptr, dx, zin, accumulate, N, H, W, C, k - 1 - pad_t, k - 1 - pad_l, stream)
                       : launch_dw_tile<5, true>(dy, w_t, nullptr, dx, zin, accumulate, N, H, W, C, k - 1 - pad_t, k - 1 - pad_l, stream);
+    if (stride == 2 && (k == 3 || k == 5)) {
+        const long long tot4 = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+        if (k == 3)
+            hipLaunchKernelGGL(dwconv_dgrad_s2_kernel<3>, dim3(blocks_for(tot4)), dim3(256), 0, (hipStream_t)stream,
+                               (const unsigned short*)dy, w_t, (unsigned short*)dx, (const unsigned short*)zin, N, H, W,
+                               C, pad_t, pad_l, P, Q, accumulate);
+        else
+            hipLaunchKernelGGL(dwconv_dgrad_s2_kernel<5>, dim3(blocks_for(tot4)), dim3(256), 0, (hipStream_t)stream,
+                               (const unsigned short*)dy, w_t, (unsigned short*)dx, (const unsigned short*)zin, N, H, W,
+                               C, pad_t, pad_l, P, Q, accumulate);
+        return check_launch("dwconv_dgrad_s2_kernel");
+    }
     const long long total = (long long)N * H * W * (C / 8);
     hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)dy, w_t, (unsigned short*)dx, (const unsigned short*)zin, N, H, W, C,
