@@ -541,11 +541,14 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(
 // block = 32 (kernel row, chunk) items x 8 row lanes; lanes reduced through LDS, one atomic per (tap, channel).
 // 8 (kernel row, chunk) items x 32 row lanes: layers have k * C/8 = 6 .. 432 items, blocks of 8 leave few idle
 constexpr int DW_U = 8, DW1_IPB = 8, DW1_PL = 32;
-template <int K, bool INSW = false>
+template <int K, bool INSW = false, int S = 1>
 __global__ __launch_bounds__(256) void dwconv_wgrad_s1_kernel(
     const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy, float* __restrict__ dw_t,
     float* __restrict__ colsum, int N, int H, int W, int C, int pad_t, int pad_l, int P, int Q, int rows_per_block,
     int qseg) {
+    // S = stride (1 or 2): the window under output pixel q starts at input column q * S - pad_l and moves S pixels
+    // per output pixel: S new loads feed K taps
+    constexpr int U = S == 1 ? DW_U : DW_U / 2;
     __shared__ float s_acc[DW1_PL][DW1_IPB][9];
     const int c8n = C >> 3;
     const int il = threadIdx.x % DW1_IPB, pl = threadIdx.x / DW1_IPB;
@@ -565,49 +568,57 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_s1_kernel(
     if (live) {
         for (int r = r0 + pl; r < r1; r += DW1_PL) {
             const int n = r / P, p = r - n * P;
-            const int h = p - pad_t + a;
+            const int h = p * S - pad_t + a;
             const bool row_ok = (unsigned)h < (unsigned)H;
             if (!row_ok && !do_cs) continue;
             const unsigned short* dyr = dy + (long long)r * Q * C + c8 * 8;
             const unsigned short* xr = x + ((long long)n * H + (row_ok ? h : 0)) * W * C + c8 * 8;
-            float win[K][8];                              // win[b] = x(h, q + b - pad_l)
+            float win[K][8];                              // win[b] = x(h, q * S + b - pad_l)
 #pragma unroll
-            for (int b = 0; b < K - 1; ++b) {
-                const int w = qa + b - pad_l;             // window of output pixel q = qa, all but the last tap
+            for (int b = 0; b < K - S; ++b) {
+                const int w = qa * S + b - pad_l;         // window of output pixel q = qa, all but the last S taps
                 if (row_ok && (unsigned)w < (unsigned)W) {
-                    load8(xr + (long long)w * C, win[b + 1]);
+                    load8(xr + (long long)w * C, win[b + S]);
                     if (INSW) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) win[b + 1][e] = bf16_to_f32(f32_to_bf16_rn(swishf(win[b + 1][e])));
+                        for (int e = 0; e < 8; ++e) win[b + S][e] = bf16_to_f32(f32_to_bf16_rn(swishf(win[b + S][e])));
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) win[b + 1][e] = 0.0f;
+                    for (int e = 0; e < 8; ++e) win[b + S][e] = 0.0f;
                 }
             }
-            // batches of DW_U pixels: all 2 * DW_U loads of a batch are issued before the first use (a thread's
-            // loop is otherwise one L2 round trip per pixel: 42 us for a 64 x 64 x 64 level against a 4 us floor)
-            for (int q0 = qa; q0 < qb; q0 += DW_U) {
-                s8v xraw[DW_U], graw[DW_U];
+            // batches of U pixels: all loads of a batch are issued before the first use (a thread's loop is
+            // otherwise one L2 round trip per pixel: 42 us for a 64 x 64 x 64 level against a 4 us floor)
+            for (int q0 = qa; q0 < qb; q0 += U) {
+                s8v xraw[U][S], graw[U];
 #pragma unroll
-                for (int u = 0; u < DW_U; ++u) {
-                    const int q = q0 + u, w = q + K - 1 - pad_l;
+                for (int u = 0; u < U; ++u) {
+                    const int q = q0 + u;
                     const s8v zero = {0, 0, 0, 0, 0, 0, 0, 0};
-                    xraw[u] = (q < qb && row_ok && (unsigned)w < (unsigned)W)
-                                  ? *reinterpret_cast<const s8v*>(xr + (long long)w * C) : zero;
+#pragma unroll
+                    for (int sx = 0; sx < S; ++sx) {
+                        const int w = q * S + K - S + sx - pad_l;
+                        xraw[u][sx] = (q < qb && row_ok && (unsigned)w < (unsigned)W)
+                                          ? *reinterpret_cast<const s8v*>(xr + (long long)w * C) : zero;
+                    }
                     graw[u] = q < qb ? *reinterpret_cast<const s8v*>(dyr + (long long)q * C) : zero;
                 }
 #pragma unroll
-                for (int u = 0; u < DW_U; ++u) {
+                for (int u = 0; u < U; ++u) {
 #pragma unroll
-                    for (int b = 0; b < K - 1; ++b)
+                    for (int b = 0; b < K - S; ++b)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) win[b][e] = win[b + 1][e];
+                        for (int e = 0; e < 8; ++e) win[b][e] = win[b + S][e];
                     float g[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        win[K - 1][e] = bf16_to_f32((unsigned short)xraw[u][e]);
-                        if (INSW) win[K - 1][e] = bf16_to_f32(f32_to_bf16_rn(swishf(win[K - 1][e])));   // x is z
+#pragma unroll
+                        for (int sx = 0; sx < S; ++sx) {
+                            float v = bf16_to_f32((unsigned short)xraw[u][sx][e]);
+                            if (INSW) v = bf16_to_f32(f32_to_bf16_rn(swishf(v)));   // x is the pre-activation z
+                            win[K - S + sx][e] = v;
+                        }
                         g[e] = bf16_to_f32((unsigned short)graw[u][e]);
                     }
                     if (do_cs) {
@@ -660,7 +671,7 @@ extern "C" int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, f
                                   void* stream) {
     MI355_REQUIRE(x && dy && dw_t && N > 0 && C > 0 && C % 8 == 0 && k > 0, "dwconv_wgrad: bad args");
     const int nrows = N * P;
-    if (stride == 1 && (k == 3 || k == 5) && P == H && Q == W) {
+    if ((stride == 1 && (k == 3 || k == 5) && P == H && Q == W) || (stride == 2 && (k == 3 || k == 5))) {
         const int items = k * (C / 8);
         const int bx = (items + DW1_IPB - 1) / DW1_IPB;
         const int qseg = 32, bz = (Q + qseg - 1) / qseg;      // column segments: a thread walks <= 32 pixels of a row
@@ -675,8 +686,16 @@ extern "C" int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, f
     hipLaunchKernelGGL((dwconv_wgrad_s1_kernel<KK, SW>), grid, dim3(256), 0, (hipStream_t)stream,                    \
                        (const unsigned short*)x, (const unsigned short*)dy, dw_t, colsum, N, H, W, C, pad_t, pad_l, \
                        P, Q, rows, qseg)
-        if (k == 3) { if (in_swish) MI355_DW1(3, true); else MI355_DW1(3, false); }
-        else        { if (in_swish) MI355_DW1(5, true); else MI355_DW1(5, false); }
+        if (stride == 2) {
+#define MI355_DW2(KK, SW)                                                                                          \
+    hipLaunchKernelGGL((dwconv_wgrad_s1_kernel<KK, SW, 2>), grid, dim3(256), 0, (hipStream_t)stream,                 \
+                       (const unsigned short*)x, (const unsigned short*)dy, dw_t, colsum, N, H, W, C, pad_t, pad_l, \
+                       P, Q, rows, qseg)
+            if (k == 3) { if (in_swish) MI355_DW2(3, true); else MI355_DW2(3, false); }
+            else        { if (in_swish) MI355_DW2(5, true); else MI355_DW2(5, false); }
+#undef MI355_DW2
+        } else if (k == 3) { if (in_swish) MI355_DW1(3, true); else MI355_DW1(3, false); }
+        else               { if (in_swish) MI355_DW1(5, true); else MI355_DW1(5, false); }
 #undef MI355_DW1
         return check_launch("dwconv_wgrad_s1_kernel");
     }

@@ -37,7 +37,9 @@ def _close(got, ref, tol):
                                             (1, 16, 16, 40, 5, 2, True), (2, 9, 7, 64, 5, 1, False),
                                             (1, 8, 8, 264 * 8, 3, 1, True), (3, 40, 70, 32, 3, 1, False),
                                             (2, 33, 35, 24, 5, 1, False), (1, 64, 64, 8, 3, 1, False),
-                                            (2, 19, 50, 48, 5, 1, True)])
+                                            (2, 19, 50, 48, 5, 1, True), (2, 17, 21, 24, 3, 2, False),
+                                            (1, 16, 16, 40, 5, 2, False), (2, 32, 70, 16, 5, 2, False),
+                                            (1, 40, 132, 8, 3, 2, True)])
 def test_depthwise_conv(N, H, W, C, k, s, sw):
     from objectdetection.pytorch_amd import ops_effdet as E
     z = _mk((N, C, H, W), 1).requires_grad_(True)
