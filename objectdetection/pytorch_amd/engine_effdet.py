@@ -15,6 +15,7 @@ backward, replayed in reverse at plan construction; gradient buffers are written
 producer and accumulated (+=) by later ones.
 """
 import ctypes
+import os
 
 import torch
 
@@ -185,16 +186,10 @@ class EffDetPlan(RetinaPlan):
         out = self.new((N, P, Q, C))
         geo = (c_int(N), c_int(H), c_int(W), c_int(C), c_int(spec.k), c_int(spec.stride), c_int(pt), c_int(pl),
                c_int(P), c_int(Q))
-        xs, insw = x, 0
-        if x_swish and spec.stride == 1:
-            # stride 1: the LDS-tiled forward and the sliding-window weight gradient apply swish as they load
-            # (once per loaded element, rounded to bf16: bit-identical to a materialised swish(z))
-            insw = 1
-        elif x_swish:
-            # stride 2 (per-tap kernels): swish ONCE per element in one elementwise pass, kept for the weight
-            # gradient, instead of once per tap inside the 9- / 25-tap loop: the expf dominated that kernel
-            xs = self.new(tuple(x.shape))
-            self._step(self.fwd_steps, 'mi355_swish_bf16', ptr(x), ptr(xs), c_i64(x.numel()))
+        # the depthwise kernels apply swish as they load a stored pre-activation (once per loaded element in the
+        # LDS-tiled forward, once per kernel row in the sliding-window weight gradient; v_exp + v_rcp, rounded to
+        # bf16 exactly like a materialised swish(z)): no elementwise pass, no second copy of the activation
+        xs, insw = x, int(bool(x_swish))
         self._step(self.fwd_steps, 'mi355_dwconv_fwd', ptr(xs), c_int(insw), ptr(spec.w_t), ptr(spec.shift),
                    ptr(out), *geo)
 
