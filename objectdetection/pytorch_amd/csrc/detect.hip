@@ -297,8 +297,12 @@ __global__ __launch_bounds__(FL_TILE) void focal_fwd_kernel(
                     const float p = fminf(fmaxf(v[k], 1e-4f), 1.0f - 1e-4f);  // losses.py:62
                     const bool one = (s == ST_POS) && (c == s_label[al]);
                     // losses.py:104-111 with gamma = 2
-                    const float fw = one ? alpha * ((1.0f - p) * (1.0f - p)) : (1.0f - alpha) * (p * p);
-                    const float bce = one ? -logf(p) : -logf(1.0f - p);
+                    // u = probability given to the true class, w = the other one: ONE logf per element, same
+                    // operations and order as the two branches of the reference formula
+                    const float q = 1.0f - p;
+                    const float u = one ? p : q, w = one ? q : p;
+                    const float fw = (one ? alpha : 1.0f - alpha) * (w * w);
+                    const float bce = -logf(u);
                     csum += fw * bce;
                 }
                 if (++c == C) { c = 0; ++al; }
@@ -488,14 +492,14 @@ __global__ __launch_bounds__(FL_TILE) void focal_bwd_kernel(
             if (s != ST_IGNORE && s != ST_NOGT && x >= 1e-4f && x <= 1.0f - 1e-4f) {
                 const float p = x;
                 const bool one = (s == ST_POS) && (c == s_label[al]);
-                float d;
-                if (one) {   // L = a (1-p)^2 (-log p)
-                    const float q = 1.0f - p;
-                    d = alpha * (2.0f * q * logf(p) - __fdiv_rn(q * q, p));
-                } else {     // L = (1-a) p^2 (-log(1-p))
-                    const float q = 1.0f - p;
-                    d = (1.0f - alpha) * (__fdiv_rn(p * p, q) - 2.0f * p * logf(q));
-                }
+                // positive: L = a (1-p)^2 (-log p)      -> dL/dp =    a  (2 q log p - q^2 / p)
+                // negative: L = (1-a) p^2 (-log(1-p))   -> dL/dp = (1-a) (p^2 / q - 2 p log q)
+                // with u = true-class probability, w = the other one both are  c (2 w log u - w^2 / u), c = a or
+                // -(1-a): one logf and one division per element, no divergent branch, bit-identical values
+                const float q = 1.0f - p;
+                const float u = one ? p : q, w = one ? q : p;
+                const float t = 2.0f * w * logf(u) - __fdiv_rn(w * w, u);
+                const float d = one ? alpha * t : (1.0f - alpha) * (-t);
                 gv = gc * d;
                 if (MODE == 1) gv *= x * (1.0f - x);     // d prob / d logit of the head sigmoid
             }
