@@ -43,6 +43,15 @@ int mi355_dw_param_grads(const float* G_t, const float* w, const float* scale, c
                          const float* mean, const float* var, float eps, int C, int k, float* dW,
                          float* dgamma, float* dbeta, int accumulate, void* stream);
 
+/* The same for every depthwise layer of a plan in one launch: a device-resident table of `n` rows (borrowed device
+ * pointers as above; dgamma / dbeta / scale / colsum / mean / var may be NULL), max_c = the largest C in it. */
+typedef struct Mi355DwGradDesc {
+    const float* G_t; const float* w; const float* scale; const float* colsum; const float* mean; const float* var;
+    float* dW; float* dgamma; float* dbeta;
+    float eps; int32_t C; int32_t T; int32_t accumulate;
+} Mi355DwGradDesc;
+int mi355_dw_param_grads_table(const Mi355DwGradDesc* table, int n, int max_c, void* stream);
+
 /* squeeze-excite (efficientnet.py:98-104) */
 /* The H*W reduction is split into `slabs` row slabs per sample (mi355_se_slabs); the reduce kernels
  * store per-slab partials [N][slabs][C] (no atomics, nothing to zero) and the tiny per-sample FC

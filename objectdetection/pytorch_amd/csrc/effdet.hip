@@ -759,6 +759,34 @@ __global__ void dw_param_grads_kernel(const float* __restrict__ G_t, const float
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + colsum[c] : colsum[c];
 }
 
+// All depthwise layers of a plan in ONE launch: blockIdx.y = row of the device-resident descriptor table
+// (48 launches of ~10 us each at the end of the EfficientDet-D0 backward otherwise).
+__global__ void dw_param_grads_table_kernel(const Mi355DwGradDesc* __restrict__ table) {
+    const Mi355DwGradDesc d = table[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    const float sc = d.scale ? d.scale[c] : 1.0f;
+    float dot = 0.0f;
+    for (int t = 0; t < d.T; ++t) {
+        const float g = d.G_t[t * d.C + c];
+        dot += d.w[c * d.T + t] * g;
+        const float v = g * sc;
+        d.dW[c * d.T + t] = d.accumulate ? d.dW[c * d.T + t] + v : v;
+    }
+    if (d.dgamma) {
+        const float dg = (1.0f / sqrtf(d.var[c] + d.eps)) * (dot - d.mean[c] * d.colsum[c]);
+        d.dgamma[c] = d.accumulate ? d.dgamma[c] + dg : dg;
+    }
+    if (d.dbeta) d.dbeta[c] = d.accumulate ? d.dbeta[c] + d.colsum[c] : d.colsum[c];
+}
+
+extern "C" int mi355_dw_param_grads_table(const Mi355DwGradDesc* table, int n, int max_c, void* stream) {
+    MI355_REQUIRE(table && n > 0 && n <= 65535 && max_c > 0, "dw_param_grads_table: bad args");
+    hipLaunchKernelGGL(dw_param_grads_table_kernel, dim3(blocks_for(max_c), (unsigned)n), dim3(256), 0,
+                       (hipStream_t)stream, table);
+    return check_launch("dw_param_grads_table_kernel");
+}
+
 extern "C" int mi355_dw_param_grads(const float* G_t, const float* w, const float* scale, const float* colsum,
                                     const float* mean, const float* var, float eps, int C, int k, float* dW,
                                     float* dgamma, float* dbeta, int accumulate, void* stream) {

@@ -38,6 +38,12 @@ class DwSpec(object):
         self.w_t = self.scale = self.shift = self.G_t = self.colsum = None
 
 
+class DwGradDesc(ctypes.Structure):
+    """Mi355DwGradDesc (include/mi355det_effdet.h)."""
+    _fields_ = [(n, c_vp) for n in ('G_t', 'w', 'scale', 'colsum', 'mean', 'var', 'dW', 'dgamma', 'dbeta')] + \
+               [('eps', c_f32), ('C', c_int), ('T', c_int), ('accumulate', c_int)]
+
+
 class SeSpec(object):
     def __init__(self, name, reduce_conv, expand_conv):
         self.name, self.reduce, self.expand = name, reduce_conv, expand_conv
@@ -559,37 +565,30 @@ class EffDetPlan(RetinaPlan):
         self._zb.zero_()
 
     def _extra_param_grads(self, arena, stream):
-        """Depthwise layers: dW = G * scale, BN gamma / beta gradients (one tiny launch per layer, marshalled once
-        per arena; independent of each other, so they alternate between the two streams)."""
-        calls = self._dw_pg_calls.get(arena) if hasattr(self, '_dw_pg_calls') else None
-        if calls is None:
-            if not hasattr(self, '_dw_pg_calls'):
-                self._dw_pg_calls = {}
-            calls = []
+        """Depthwise layers: dW = G * scale, frozen-BN gamma / beta gradients — one table-driven launch for all of
+        them (the descriptor table is built once per gradient arena)."""
+        tabs = self.__dict__.setdefault('_dw_pg_tables', {})
+        tab = tabs.get(arena)
+        if tab is None:
+            rows = []
             for s in self.dw_specs:
                 bn = s.bn
-                calls.append((s.name, (
-                    ptr(s.G_t), ptr(s.conv.weight), ptr(s.scale), ptr(s.colsum if bn is not None else None),
-                    ptr(bn.running_mean if bn is not None else None), ptr(bn.running_var if bn is not None else None),
-                    c_f32(bn.eps if bn is not None else 0.0), c_int(s.C), c_int(s.k),
-                    ptr(self.grad_view(s.conv.weight, arena)),
-                    ptr(self.grad_view(bn.weight, arena) if bn is not None else None),
-                    ptr(self.grad_view(bn.bias, arena) if bn is not None else None), c_int(1))))
-            self._dw_pg_calls[arena] = calls
-            self.keep.append(calls)
-        st = c_vp(stream)
-        side = self._side_stream() if self._side_active() else None
-        if side is not None:
-            ss = c_vp(side.cuda_stream)
-            self.lib.mi355_stream_fork(st, ss)
-        fn = self.lib.mi355_dw_param_grads
-        for i, (name, args) in enumerate(calls):
-            rc = fn(*args, ss if (side is not None and i & 1) else st)
-            if rc:
-                raise _lib.Mi355Error('dw_param_grads(%s): %s' % (name, self.lib.mi355_last_error().decode()))
-        if side is not None:
-            self._side_dirty = True
-            self.join_side()
+
+                def dp(t):
+                    return 0 if t is None else t.data_ptr()
+                rows.append(DwGradDesc(
+                    dp(s.G_t), dp(s.conv.weight), dp(s.scale), dp(s.colsum if bn is not None else None),
+                    dp(bn.running_mean if bn is not None else None), dp(bn.running_var if bn is not None else None),
+                    dp(self.grad_view(s.conv.weight, arena)),
+                    dp(self.grad_view(bn.weight, arena) if bn is not None else None),
+                    dp(self.grad_view(bn.bias, arena) if bn is not None else None),
+                    float(bn.eps) if bn is not None else 0.0, s.C, s.k * s.k, 1))
+            arr = (DwGradDesc * len(rows))(*rows)
+            dev_tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.dev)
+            tab = (dev_tab, len(rows), max(s.C for s in self.dw_specs))
+            tabs[arena] = tab
+        if tab[1]:
+            _lib.call('mi355_dw_param_grads_table', ptr(tab[0]), c_int(tab[1]), c_int(tab[2]), c_vp(stream))
 
     def run_heads(self, img):
         self._zf.zero_()
