@@ -43,6 +43,20 @@ int mi355_dw_param_grads(const float* G_t, const float* w, const float* scale, c
                          const float* mean, const float* var, float eps, int C, int k, float* dW,
                          float* dgamma, float* dbeta, int accumulate, void* stream);
 
+/* Start-of-step preparation of every depthwise layer in one launch: frozen-BN fold (scale = gamma / sqrt(var + eps),
+ * shift = beta - mean * scale; gamma NULL: plain conv, scale / shift untouched) and w_t[t][c] = w[c][t] * scale[c]
+ * (= mi355_bn_fold + mi355_dw_prep_weight per row).  max_elems = the largest C * T in the table. */
+typedef struct Mi355DwPrepDesc {
+    const float* gamma; const float* beta; const float* mean; const float* var; const float* w;
+    float* scale; float* shift; float* w_t;
+    float eps; int32_t C; int32_t T; int32_t pad_;
+} Mi355DwPrepDesc;
+int mi355_dw_prep_table(const Mi355DwPrepDesc* table, int n, int max_elems, void* stream);
+/* Fast-attention fusion weights of every BiFPN node in one launch: w[0..2] = relu(p) / (sum relu(p) + eps)
+ * (efficientdet.py:213-265), rows of (parameter, its length 2 or 3, output). */
+typedef struct Mi355FusionDesc { const float* p; float* w; int32_t n; int32_t pad_; } Mi355FusionDesc;
+int mi355_fusion_weights_table(const Mi355FusionDesc* table, int rows, float eps, void* stream);
+
 /* The same for every depthwise layer of a plan in one launch: a device-resident table of `n` rows (borrowed device
  * pointers as above; dgamma / dbeta / scale / colsum / mean / var may be NULL), max_c = the largest C in it. */
 typedef struct Mi355DwGradDesc {

@@ -60,6 +60,31 @@ extern "C" int mi355_dw_prep_weight(const float* w, const float* scale, int C, i
     return check_launch("dw_prep_weight_kernel");
 }
 
+// Every depthwise layer of a plan in one launch (blockIdx.y = table row): frozen-BN fold (same arithmetic as
+// bn_fold_kernel, conv_aux.hip) + transposed, scaled taps.  96 tiny launches at the start of an EfficientDet-D0 step otherwise.
+__global__ void dw_prep_table_kernel(const Mi355DwPrepDesc* __restrict__ table) {
+    const Mi355DwPrepDesc d = table[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.C * d.T) return;
+    const int t = i / d.C, c = i - t * d.C;
+    float sc = 1.0f;
+    if (d.gamma) {
+        sc = d.gamma[c] / sqrtf(d.var[c] + d.eps);
+        if (t == 0) {
+            d.scale[c] = sc;
+            d.shift[c] = d.beta[c] - d.mean[c] * sc;
+        }
+    }
+    d.w_t[i] = d.w[c * d.T + t] * sc;
+}
+
+extern "C" int mi355_dw_prep_table(const Mi355DwPrepDesc* table, int n, int max_elems, void* stream) {
+    MI355_REQUIRE(table && n > 0 && n <= 65535 && max_elems > 0, "dw_prep_table: bad args");
+    hipLaunchKernelGGL(dw_prep_table_kernel, dim3(blocks_for(max_elems), (unsigned)n), dim3(256), 0,
+                       (hipStream_t)stream, table);
+    return check_launch("dw_prep_table_kernel");
+}
+
 template <bool SWISH>
 __global__ void dwconv_fwd_kernel(const unsigned short* __restrict__ in, const float* __restrict__ w_t,
                                   const float* __restrict__ bias, unsigned short* __restrict__ out, int N, int H,
@@ -1090,6 +1115,21 @@ extern "C" int mi355_fusion_weights_fwd(const float* p, int n, float eps, float*
     MI355_REQUIRE(p && w && n >= 1 && n <= 3, "fusion_weights_fwd: bad args");
     hipLaunchKernelGGL(fusion_weights_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, n, eps, w);
     return check_launch("fusion_weights_fwd_kernel");
+}
+// all fusion nodes of a plan: rows of (p, n, w) pointers, one thread each
+__global__ void fusion_weights_table_kernel(const Mi355FusionDesc* __restrict__ table, int rows, float eps) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const Mi355FusionDesc d = table[r];
+    float s = 0.0f;
+    for (int i = 0; i < d.n; ++i) s += fmaxf(d.p[i], 0.0f);
+    for (int i = 0; i < 3; ++i) d.w[i] = i < d.n ? fmaxf(d.p[i], 0.0f) / (s + eps) : 0.0f;
+}
+extern "C" int mi355_fusion_weights_table(const Mi355FusionDesc* table, int rows, float eps, void* stream) {
+    MI355_REQUIRE(table && rows > 0, "fusion_weights_table: bad args");
+    hipLaunchKernelGGL(fusion_weights_table_kernel, dim3(blocks_for(rows)), dim3(256), 0, (hipStream_t)stream, table,
+                       rows, eps);
+    return check_launch("fusion_weights_table_kernel");
 }
 __global__ void fusion_weights_bwd_kernel(const float* p, int n, float eps, const float* gw, float* gp) {
     if (threadIdx.x != 0) return;

@@ -44,6 +44,17 @@ class DwGradDesc(ctypes.Structure):
                [('eps', c_f32), ('C', c_int), ('T', c_int), ('accumulate', c_int)]
 
 
+class DwPrepDesc(ctypes.Structure):
+    """Mi355DwPrepDesc (include/mi355det_effdet.h)."""
+    _fields_ = [(n, c_vp) for n in ('gamma', 'beta', 'mean', 'var', 'w', 'scale', 'shift', 'w_t')] + \
+               [('eps', c_f32), ('C', c_int), ('T', c_int), ('pad_', c_int)]
+
+
+class FusionDesc(ctypes.Structure):
+    """Mi355FusionDesc (include/mi355det_effdet.h)."""
+    _fields_ = [('p', c_vp), ('w', c_vp), ('n', c_int), ('pad_', c_int)]
+
+
 class SeSpec(object):
     def __init__(self, name, reduce_conv, expand_conv):
         self.name, self.reduce, self.expand = name, reduce_conv, expand_conv
@@ -136,16 +147,25 @@ class EffDetPlan(RetinaPlan):
     # ------------------------------------------------------------------ prep
     def _build_prep(self):
         super(EffDetPlan, self)._build_prep()
-        for i, s in enumerate(self.dw_specs):
-            self._mark_side = bool(i & 1)             # independent tiny launches: every other layer on the side stream
-            if s.bn is not None:
-                bn = s.bn
-                self._step(self.prep_steps, 'mi355_bn_fold', ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
-                           ptr(bn.running_var), c_vp(0), c_f32(bn.eps), c_int(s.C), ptr(s.scale), ptr(s.shift))
+        # every depthwise layer's frozen-BN fold + tap transpose in ONE table-driven launch
+        rows = []
+        for s in self.dw_specs:
             assert s.conv.weight.is_contiguous()
-            self._step(self.prep_steps, 'mi355_dw_prep_weight', ptr(s.conv.weight), ptr(s.scale), c_int(s.C),
-                       c_int(s.k), ptr(s.w_t))
-        self._mark_side = False
+            bn = s.bn
+
+            def dp(t):
+                return 0 if t is None else t.data_ptr()
+            rows.append(DwPrepDesc(dp(bn.weight if bn is not None else None), dp(bn.bias if bn is not None else None),
+                                   dp(bn.running_mean if bn is not None else None),
+                                   dp(bn.running_var if bn is not None else None), dp(s.conv.weight),
+                                   dp(s.scale), dp(s.shift), dp(s.w_t),
+                                   float(bn.eps) if bn is not None else 0.0, s.C, s.k * s.k, 0))
+        if rows:
+            arr = (DwPrepDesc * len(rows))(*rows)
+            self._dw_prep_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.dev)
+            self._step(self.prep_steps, 'mi355_dw_prep_table', ptr(self._dw_prep_table), c_int(len(rows)),
+                       c_int(max(s.C * s.k * s.k for s in self.dw_specs)))
+        self._fusion_rows, self._fusion_table = [], None
 
     # ------------------------------------------------------------------ gradient bookkeeping (build time)
     def grad(self, t):
@@ -274,7 +294,7 @@ class EffDetPlan(RetinaPlan):
         else:
             n = param.numel()
             w = self.new((4,), torch.float32, zero=True)
-            self._step(self.prep_steps, 'mi355_fusion_weights_fwd', ptr(param), c_int(n), c_f32(1e-4), ptr(w))
+            self._fusion_rows.append(FusionDesc(param.data_ptr(), w.data_ptr(), n, 0))   # one launch for all nodes
         N, H, W, C = in0.shape
         z = self.new(tuple(in0.shape))
         dims = (c_int(N), c_int(H), c_int(W), c_int(C))
@@ -592,6 +612,11 @@ class EffDetPlan(RetinaPlan):
 
     def run_heads(self, img):
         self._zf.zero_()
+        if self._fusion_table is None and self._fusion_rows:
+            arr = (FusionDesc * len(self._fusion_rows))(*self._fusion_rows)
+            self._fusion_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.dev)
+            self._step(self.prep_steps, 'mi355_fusion_weights_table', ptr(self._fusion_table),
+                       c_int(len(self._fusion_rows)), c_f32(1e-4))
         if self.drop_connect and self._dc_rows:
             if self.dc_inject is not None:
                 self.dc_u[:self.dc_inject.shape[0]].copy_(self.dc_inject)
