@@ -57,6 +57,10 @@ int mi355_dw_prep_table(const Mi355DwPrepDesc* table, int n, int max_elems, void
 typedef struct Mi355FusionDesc { const float* p; float* w; int32_t n; int32_t pad_; } Mi355FusionDesc;
 int mi355_fusion_weights_table(const Mi355FusionDesc* table, int rows, float eps, void* stream);
 
+/* ... and their backward (gp = d loss / d p from gw = d loss / d w) for all nodes in one launch. */
+typedef struct Mi355FusionBwdDesc { const float* p; const float* gw; float* gp; int32_t n; int32_t pad_; } Mi355FusionBwdDesc;
+int mi355_fusion_weights_bwd_table(const Mi355FusionBwdDesc* table, int rows, float eps, void* stream);
+
 /* The same for every depthwise layer of a plan in one launch: a device-resident table of `n` rows (borrowed device
  * pointers as above; dgamma / dbeta / scale / colsum / mean / var may be NULL), max_c = the largest C in it. */
 typedef struct Mi355DwGradDesc {

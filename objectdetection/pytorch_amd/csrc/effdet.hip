@@ -1138,6 +1138,20 @@ __global__ void fusion_weights_bwd_kernel(const float* p, int n, float eps, cons
     // w_i = r_i / s  ->  dL/dr_j = gw_j / s - dot / s^2 ; relu'
     for (int j = 0; j < n; ++j) gp[j] = p[j] > 0.0f ? (gw[j] / s - dot / (s * s)) : 0.0f;
 }
+__global__ void fusion_weights_bwd_table_kernel(const Mi355FusionBwdDesc* __restrict__ table, int rows, float eps) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const Mi355FusionBwdDesc d = table[r];
+    float s = eps, dot = 0.0f;
+    for (int i = 0; i < d.n; ++i) { const float v = fmaxf(d.p[i], 0.0f); s += v; dot += d.gw[i] * v; }
+    for (int j = 0; j < d.n; ++j) d.gp[j] = d.p[j] > 0.0f ? (d.gw[j] / s - dot / (s * s)) : 0.0f;
+}
+extern "C" int mi355_fusion_weights_bwd_table(const Mi355FusionBwdDesc* table, int rows, float eps, void* stream) {
+    MI355_REQUIRE(table && rows > 0, "fusion_weights_bwd_table: bad args");
+    hipLaunchKernelGGL(fusion_weights_bwd_table_kernel, dim3(blocks_for(rows)), dim3(256), 0, (hipStream_t)stream,
+                       table, rows, eps);
+    return check_launch("fusion_weights_bwd_table_kernel");
+}
 extern "C" int mi355_fusion_weights_bwd(const float* p, int n, float eps, const float* gw, float* gp, void* stream) {
     MI355_REQUIRE(p && gw && gp && n >= 1 && n <= 3, "fusion_weights_bwd: bad args");
     hipLaunchKernelGGL(fusion_weights_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, n, eps, gw, gp);

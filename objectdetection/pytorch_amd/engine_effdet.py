@@ -55,6 +55,11 @@ class FusionDesc(ctypes.Structure):
     _fields_ = [('p', c_vp), ('w', c_vp), ('n', c_int), ('pad_', c_int)]
 
 
+class FusionBwdDesc(ctypes.Structure):
+    """Mi355FusionBwdDesc (include/mi355det_effdet.h)."""
+    _fields_ = [('p', c_vp), ('gw', c_vp), ('gp', c_vp), ('n', c_int), ('pad_', c_int)]
+
+
 class SeSpec(object):
     def __init__(self, name, reduce_conv, expand_conv):
         self.name, self.reduce, self.expand = name, reduce_conv, expand_conv
@@ -309,8 +314,7 @@ class EffDetPlan(RetinaPlan):
                 gw = self._zero_bwd_alloc(4)
                 self._step(self.bwd_steps, 'mi355_bifpn_node_wgrad', ptr(gz), ptr(in0), ptr(in1), c_int(int(up1)),
                            ptr(in2), ptr(gw), *dims)
-                self._fusion_bwd.append((param, n, gw))
-                self._step(self.bwd_steps, '__fusion_bwd__', len(self._fusion_bwd) - 1)
+                self._fusion_bwd.append((param, n, gw))      # all nodes: one table launch behind the backward list
             self._axpy(gz, w, 0, self.grad(in0), not self.first_write(in0))
             if up1:
                 self._step(self.bwd_steps, 'mi355_upsample_bwd_axpy', ptr(gz), ptr(w), c_int(1), ptr(self.grad(in1)),
@@ -565,9 +569,7 @@ class EffDetPlan(RetinaPlan):
                                              ptr(self.grad_view(spec.expand.bias, arena)),
                                              c_int(N), c_int(spec.C), c_int(spec.Cse), s)
                 else:
-                    param, n, gw = self._fusion_bwd[args[0]]
-                    rc = lib.mi355_fusion_weights_bwd(ptr(param), c_int(n), c_f32(1e-4), ptr(gw),
-                                                      ptr(self.grad_view(param, arena)), s)
+                    raise _lib.Mi355Error('unknown deferred step %r' % (name,))
             else:
                 rc = fn(*args, s)
             if rc:
@@ -609,6 +611,17 @@ class EffDetPlan(RetinaPlan):
             tabs[arena] = tab
         if tab[1]:
             _lib.call('mi355_dw_param_grads_table', ptr(tab[0]), c_int(tab[1]), c_int(tab[2]), c_vp(stream))
+        if self._fusion_bwd:
+            ftabs = self.__dict__.setdefault('_fusion_bwd_tables', {})
+            ftab = ftabs.get(arena)
+            if ftab is None:
+                rows = [FusionBwdDesc(p.data_ptr(), gw.data_ptr(), self.grad_view(p, arena).data_ptr(), n, 0)
+                        for p, n, gw in self._fusion_bwd]
+                arr = (FusionBwdDesc * len(rows))(*rows)
+                ftab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.dev)
+                ftabs[arena] = ftab
+            _lib.call('mi355_fusion_weights_bwd_table', ptr(ftab), c_int(len(self._fusion_bwd)), c_f32(1e-4),
+                      c_vp(stream))
 
     def run_heads(self, img):
         self._zf.zero_()
