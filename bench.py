@@ -142,14 +142,18 @@ def conv_bytes(plan):
 
 
 def measured_traffic(args):
-    """HBM-side bytes per step of the conv kernels from the committed PMC passes (tools/collect_traffic.py;
-    FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950); only for the workload the
-    passes were taken on."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    if not (args.arch == 'retinanet' and args.depth == 50 and args.size == 512 and args.batch == 16 and os.path.exists(path)):
+    """HBM-side bytes per step of the conv kernels from the COMMITTED PMC passes (tools/collect_traffic.py;
+    FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950): a kept profile of the same
+    command, not a measurement of this run (`traffic_source: "committed"`); only for the workload the passes
+    were taken on."""
+    if not (args.arch == 'retinanet' and args.depth == 50 and args.size == 512 and args.batch == 16):
         return None, None
-    t = json.load(open(path))
-    return t['conv_kernels_bytes_per_step'], 'profiles/r01_pmc_traffic.json'
+    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path):
+            t = json.load(open(path))
+            return t['conv_kernels_bytes_per_step'], 'profiles/' + name
+    return None, None
 
 
 def time_conv_kernels(plan, iters):
@@ -230,8 +234,28 @@ def infer_bench(args, model, name, img, dev):
     print(json.dumps(out))
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: this parent (which has not touched the GPU:
+    importing torch does not initialise HIP) starts the N ranks through torch.distributed.run, one per GPU,
+    and returns their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%s (launch one rank per GPU: python -m torch.distributed.run '
+                 '--nproc-per-node %d ... bench.py --gpus %d)' % (args.gpus, os.environ.get('WORLD_SIZE', '1'),
+                                                                 args.gpus, args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -289,24 +313,40 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # per-step HIP events on the launch stream (every step ends there: the plan joins its side stream): no sync
+    # inside the timed region; the MEDIAN step time is reported beside the mean the headline value is made of
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    own_ms = 1e3 * elapsed / args.steps
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    ranks_seen, per_rank_ms = 1, [round(own_ms, 3)]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                         # collective-verified rank count
+        ranks_seen = int(ones.item())
+        allms = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allms, torch.tensor([own_ms], device=dev, dtype=torch.float64))
+        per_rank_ms = [round(float(x.item()), 3) for x in allms]
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
     out = {
         'metric': 'images/sec training (%s, %dx%d, bs=%d/GPU)' % (name, S, S, B),
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'ms_per_step_median': round(median_ms, 3),
+        'ranks_seen': ranks_seen, 'ms_per_step_per_rank': per_rank_ms, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': '%s, %dx%d, bf16 MFMA convs (fp32 accumulate, fp32 loss '
                                'and optimizer), batch=%d/GPU, fwd+FocalLoss+bwd+clip+AdamW, frozen BN'
@@ -324,7 +364,8 @@ def main():
         traffic, src = measured_traffic(args)
         out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-                           'traffic_note': 'HBM-side bytes of the conv kernels per step (PMC, %s)' % src if src else None,
+                           'traffic_source': 'committed' if src else None,
+                           'traffic_note': 'HBM-side bytes of the conv kernels per step (PMC passes of the same command, kept in %s; not measured in this run)' % src if src else None,
                            'algorithmic_bytes_per_step': round(conv_bytes(plan)),
                            'kernel': 'conv_gather(+row3, split-K) + conv_wgrad kernels (%d launches/step)' % nlaunch,
                            'algorithmic_gflop_per_image': round(train_f / B / 1e9, 2),

@@ -66,7 +66,7 @@ int mi355_focal_loss_fwd(const float* cls, const float* reg, const float* anchor
  * rows the head convs consume: element offset of grad_cls (b, a, c) =
  * (b*(A/cell_anchors) + a/cell_anchors)*cls_cell_pitch + (a%cell_anchors)*C + c, of grad_reg
  * (b, a, j) = (...)*reg_cell_pitch + (a%cell_anchors)*4 + j  (pad columns are never written:
- * zero the buffers once). */
+ * zero the buffers once).  grad_cls_mode 2 = mode 1 with fp32 elements (the fp32-accurate conv mode). */
 int mi355_focal_loss_bwd(const float* cls, const float* reg, const float* anchors,
                          const float* annot, const int32_t* argmax, const int8_t* state,
                          const int32_t* num_pos, const float* grad_losses, int B, int A, int C,

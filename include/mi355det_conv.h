@@ -132,6 +132,8 @@ typedef struct Mi355LayerDesc {
     int32_t atomic;          /* grads: != 0 when another descriptor writes the same dW / dbias
                                 (weights shared across pyramid levels): use atomics */
     int32_t nslabs;          /* grads: G / colsum hold this many split-K slabs (0 or 1: a single buffer) */
+    int32_t f32_shadows;     /* prep: != 0 writes w_fwd / w_dgr as fp32 (the fp32-accurate mode) instead of bf16 */
+    int32_t reserved;
     const float* gamma;      /* frozen BN (all four NULL when the layer has no BN) */
     const float* beta;
     const float* mean;
@@ -152,6 +154,22 @@ typedef struct Mi355LayerDesc {
 } Mi355LayerDesc;
 int mi355_prep_weights_table(const Mi355LayerDesc* d_table, int nlayers, int nblocks, void* stream);
 int mi355_param_grads_table(const Mi355LayerDesc* d_table, int nlayers, int nblocks, void* stream);
+
+/* ---- fp32-accurate mode (MI355_CONV_PRECISION=fp32) ------------------------------------------------
+ * The reference trains in fp32 (train.py:259-321: no autocast).  These entry points take the SAME launch
+ * descriptors as the bf16 ones above, with every activation / gradient / weight-shadow pointer read as
+ * fp32 (strides stay in elements, C a multiple of 4) and run the contraction on the exact-f32 matrix
+ * instruction v_mfma_f32_16x16x4_f32.  Output is always fp32 (`out_f32` is ignored). */
+int mi355_conv_gather_f32(const Mi355ConvLaunch* launch, void* stream);
+/* slab_stride == 0: fp32 atomics straight into `ws` (= dW; zero it first), colsum likewise. */
+int mi355_conv_wgrad_slabs_f32(const Mi355ConvLaunch* launch, float* ws, int64_t slab_stride, int max_slabs,
+                               float* colsum, int split_rows, void* stream);
+int mi355_nchw_to_nhwc_f32(const float* in, float* out, int N, int C, int H, int W, int Cpad, void* stream);
+int mi355_maxpool3x3s2_fwd_f32(const float* in, float* out, int8_t* idx, int N, int H, int W, int C, void* stream);
+int mi355_maxpool3x3s2_bwd_f32(const float* gout, const int8_t* idx, float* gin, const float* relu_mask,
+                               int N, int H, int W, int C, void* stream);
+int mi355_sumpool2x2_f32(const float* src, float* dst, int N, int H, int W, int C, int accumulate, void* stream);
+int mi355_relu_mask_f32(const float* x, const float* ref, float* y, int64_t n, void* stream);
 
 /* MaxPool 3x3 s2 p1 (retinanet.py:188) NHWC bf16; idx int8 [N][P][Q][C] = argmax window slot. */
 int mi355_maxpool3x3s2_fwd(const void* in, void* out, int8_t* idx, int N, int H, int W, int C,

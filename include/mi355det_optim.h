@@ -36,6 +36,17 @@ int mi355_adamw_flat(float* param, float* grad, float* m, float* v, int64_t n, f
                      float beta2, float eps, float weight_decay, const void* state, int scale_grad,
                      void* stream);
 
+/* The same two passes with a skip table: `skip_ranges` = device int64 [nskip][2], sorted disjoint arena ranges
+ * [lo, hi) of elements that neither count in the norm nor are updated (no weight decay either).  These are
+ * the parameters torch's clip_grad_norm_ / AdamW skip because `p.grad is None`: requires_grad == False
+ * (the head-only fine-tune of train.py:206-216) and parameters no forward uses (the BiFPN fusion weights of
+ * EfficientDet-D6/D7 with attention=False, efficientdet.py:269-317).  nskip == 0: the plain passes. */
+int mi355_grad_sumsq_masked(const float* grad, int64_t n, float* partials, const int64_t* skip_ranges, int nskip,
+                            void* stream);
+int mi355_adamw_flat_masked(float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, const void* state, int scale_grad,
+                            const int64_t* skip_ranges, int nskip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,11 +97,18 @@ class _TrainStep(torch.autograd.Function):
     def forward(ctx, plan, anchors, img, annot, *params):
         plan.run_heads(img)
         losses_ = plan.run_loss(anchors, annot)
-        ctx.plan = plan
+        ctx.plan, ctx.serial = plan, plan.forward_serial
         return losses_[0:1].clone(), losses_[1:2].clone()
 
     @staticmethod
     def backward(ctx, g_cls, g_reg):
+        if ctx.serial != ctx.plan.forward_serial:
+            # the reference's autograd graph keeps per-call activations; the launch plan keeps ONE set per
+            # (batch, H, W): a second forward on the same shape (validation call, return_head, a second
+            # micro-batch) before this backward overwrote what it needs
+            raise RuntimeError('mi355det: another forward ran on this launch plan (shape %dx%dx%d) between this '
+                               'loss\'s forward and its backward; call backward() before the next forward of '
+                               'the same input shape' % (ctx.plan.B, ctx.plan.H, ctx.plan.W))
         grads = ctx.plan.run_backward(g_cls, g_reg)
         return (None, None, None, None) + tuple(grads)
 
@@ -192,10 +199,10 @@ class RetinaNet(nn.Module):
                                '(there is no CPU fallback)' % img.device)
         if getattr(self, '_bn_list', None) is None:          # (module objects are stable; `.training` is read live)
             self._bn_list = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
-        for m in self._bn_list:
-            if m.training:
-                raise RuntimeError('train-mode BatchNorm is not on the frozen-BN hot path: call '
-                                   'freeze_bn() as train.py:273-277 does')
+        # frozen BN (train.py:273-277, the reference loop) is folded into the convs; layers left in train mode (or
+        # made SynchronizedBatchNorm2d by utils.utils.replace_w_sync_bn) get batch-statistics passes in the plan
+        bn_sig = tuple(m.training for m in self._bn_list)
+        bn_sig = bn_sig if any(bn_sig) else ()
         w = self.conv1.weight
         if w.device != img.device:
             raise RuntimeError('model on %s, input on %s' % (w.device, img.device))
@@ -203,6 +210,10 @@ class RetinaNet(nn.Module):
                for m in self.modules()) if not self._plans else False:
             self._channels_last_params()
         key = (img.shape[0], img.shape[2], img.shape[3], img.device.index)
+        if engine.precision_of(self) != 'bf16':          # (bf16 keys stay 4-tuples)
+            key = key + (engine.precision_of(self),)
+        if bn_sig:
+            key = key + (bn_sig,)
         return _cached_plan(self, key, lambda: self._plan_class(self, img.shape[0], img.shape[2], img.shape[3],
                                                                 img.device))
 

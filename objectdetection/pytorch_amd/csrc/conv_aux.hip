@@ -419,18 +419,25 @@ __global__ __launch_bounds__(256) void prep_weights_table_kernel(const Mi355Laye
     __syncthreads();
     unsigned short* w_fwd = (unsigned short*)d.w_fwd;
     unsigned short* w_dgr = (unsigned short*)d.w_dgr;
+    const bool f32 = d.f32_shadows != 0;               // fp32-accurate mode: the shadows stay fp32
     for (int j = ty; j < 32; j += 8) {
         const int k = k0 + j, c = c0 + tx;
         float v = 0.0f;
         if (k < d.K && c < d.C) v = d.w[k * d.sk + c * d.sc + r * d.sr + s * d.ss] * s_scale[j];
         tile[j][tx] = v;
-        if (k < d.K && c < d.Cpad) w_fwd[((long long)k * T + rs) * d.Cpad + c] = f32_to_bf16_rn(v);
+        if (k < d.K && c < d.Cpad) {
+            if (f32) ((float*)d.w_fwd)[((long long)k * T + rs) * d.Cpad + c] = v;
+            else w_fwd[((long long)k * T + rs) * d.Cpad + c] = f32_to_bf16_rn(v);
+        }
     }
     __syncthreads();
     if (w_dgr) {
         for (int j = ty; j < 32; j += 8) {
             const int c = c0 + j, k = k0 + tx;
-            if (c < d.C && k < d.Kpad) w_dgr[((long long)c * T + rs) * d.Kpad + k] = f32_to_bf16_rn(tile[tx][j]);
+            if (c < d.C && k < d.Kpad) {
+                if (f32) ((float*)d.w_dgr)[((long long)c * T + rs) * d.Kpad + k] = tile[tx][j];
+                else w_dgr[((long long)c * T + rs) * d.Kpad + k] = f32_to_bf16_rn(tile[tx][j]);
+            }
         }
     }
 }

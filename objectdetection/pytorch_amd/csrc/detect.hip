@@ -451,6 +451,15 @@ __global__ __launch_bounds__(FL_TILE) void focal_bwd_kernel(
         }
         if (MODE == 0) {
             reinterpret_cast<float4*>(grad_reg)[(size_t)b * A + a] = make_float4(g4[0], g4[1], g4[2], g4[3]);
+        } else if (MODE == 2) {                    // fp32-accurate mode: fp32 rows, cell layout as mode 1
+            float* dst = reinterpret_cast<float*>(grad_reg);
+            if (cell_anchors > 0) {
+                const int cell = a / cell_anchors, j = a - cell * cell_anchors;
+                dst += ((size_t)b * (A / cell_anchors) + cell) * cell_pitch + j * 4;
+            } else {
+                dst += ((size_t)b * A + a) * 4;
+            }
+            dst[0] = g4[0]; dst[1] = g4[1]; dst[2] = g4[2]; dst[3] = g4[3];
         } else {
             ushort4 o;
             o.x = f32_to_bf16(g4[0]); o.y = f32_to_bf16(g4[1]);
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(FL_TILE) void focal_bwd_kernel(
                 const float t = 2.0f * w * logf(u) - __fdiv_rn(w * w, u);
                 const float d = one ? alpha * t : (1.0f - alpha) * (-t);
                 gv = gc * d;
-                if (MODE == 1) gv *= x * (1.0f - x);     // d prob / d logit of the head sigmoid
+                if (MODE != 0) gv *= x * (1.0f - x);     // d prob / d logit of the head sigmoid
             }
             g[k] = gv;
             if (++c == C) { c = 0; ++al; }
@@ -510,6 +519,17 @@ __global__ __launch_bounds__(FL_TILE) void focal_bwd_kernel(
             float* o = reinterpret_cast<float*>(grad_cls) + tbase;
             if (VEC == 4) reinterpret_cast<float4*>(o)[i] = make_float4(g[0], g[1 % VEC], g[2 % VEC], g[3 % VEC]);
             else o[i] = g[0];
+        } else if (MODE == 2) {
+            const int aa = a0 + e0 / C, cc = e0 - (e0 / C) * C;
+            float* o = reinterpret_cast<float*>(grad_cls);
+            if (cell_anchors > 0) {
+                const int cell = aa / cell_anchors;
+                o += ((size_t)b * (A / cell_anchors) + cell) * cls_pitch + (size_t)(aa - cell * cell_anchors) * C + cc;
+            } else {
+                o += tbase + e0;
+            }
+            if (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(g[0], g[1 % VEC], g[2 % VEC], g[3 % VEC]);
+            else o[0] = g[0];
         } else if (cell_anchors > 0) {
             // NHWC head-gradient rows: (cell, anchor-in-cell, class) with a padded cell pitch
             const int aa = a0 + e0 / C, cc = e0 - (e0 / C) * C;
@@ -549,8 +569,8 @@ extern "C" int mi355_focal_loss_bwd(const float* cls, const float* reg, const fl
                   grad_reg, "focal_loss_bwd: null pointer");
     MI355_REQUIRE(B > 0 && B <= 65535 && A > 0 && C > 0 && M >= 0, "focal_loss_bwd: bad shape");
     MI355_REQUIRE((int64_t)M * 24 <= 96 * 1024, "focal_loss_bwd: M too large");
-    MI355_REQUIRE(grad_mode == 0 || grad_mode == 1, "focal_loss_bwd: grad_mode");
-    MI355_REQUIRE(cell_anchors == 0 || (grad_mode == 1 && A % cell_anchors == 0 &&
+    MI355_REQUIRE(grad_mode >= 0 && grad_mode <= 2, "focal_loss_bwd: grad_mode");
+    MI355_REQUIRE(cell_anchors == 0 || (grad_mode >= 1 && A % cell_anchors == 0 &&
                                         reg_cell_pitch >= cell_anchors * 4 && reg_cell_pitch % 4 == 0 &&
                                         cls_cell_pitch >= cell_anchors * C && cls_cell_pitch % 4 == 0),
                   "focal_loss_bwd: bad cell layout");
@@ -562,8 +582,8 @@ extern "C" int mi355_focal_loss_bwd(const float* cls, const float* reg, const fl
     hipLaunchKernelGGL((focal_bwd_kernel<V, MD>), grid, block, lds, (hipStream_t)stream, cls,    \
                        reg, (const float4*)anchors, annot, argmax, state, num_pos, grad_losses,  \
                        B, A, C, M, alpha, grad_cls, grad_reg, cell_anchors, cls_cell_pitch, reg_cell_pitch)
-    if (vec4) { if (grad_mode == 0) LAUNCH_BWD(4, 0); else LAUNCH_BWD(4, 1); }
-    else      { if (grad_mode == 0) LAUNCH_BWD(1, 0); else LAUNCH_BWD(1, 1); }
+    if (vec4) { if (grad_mode == 0) LAUNCH_BWD(4, 0); else if (grad_mode == 1) LAUNCH_BWD(4, 1); else LAUNCH_BWD(4, 2); }
+    else      { if (grad_mode == 0) LAUNCH_BWD(1, 0); else if (grad_mode == 1) LAUNCH_BWD(1, 1); else LAUNCH_BWD(1, 2); }
 #undef LAUNCH_BWD
     return check_launch("focal_bwd_kernel");
 }

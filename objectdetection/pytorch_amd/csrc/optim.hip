@@ -8,18 +8,41 @@ using namespace mi355;
 
 namespace {
 struct OptState { int step; float clip_coef; float skip; float grad_norm; };
+
+// Elements the reference's optimizer never touches: parameters with requires_grad == False and parameters that
+// no forward uses (`p.grad is None`: torch's clip_grad_norm_ and AdamW skip them, train.py:320-321), as sorted,
+// disjoint arena ranges [lo, hi).  `true` = element i is skipped.
+__device__ __forceinline__ bool in_ranges(const long long* __restrict__ r, int n, long long i) {
+    int lo = 0, hi = n;                          // first range with hi > i
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (r[2 * mid + 1] > i) hi = mid; else lo = mid + 1;
+    }
+    return lo < n && r[2 * lo] <= i;
+}
 }
 
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float4* __restrict__ g4, const float* __restrict__ g,
-                                                         long long n, float* __restrict__ partials) {
+                                                         long long n, float* __restrict__ partials,
+                                                         const long long* __restrict__ skip, int nskip) {
     __shared__ float red[4];
     const long long n4 = n >> 2;
     float acc = 0.0f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const float4 v = g4[i];
+        float4 v = g4[i];
+        if (nskip > 0) {
+            if (in_ranges(skip, nskip, 4 * i)) v.x = 0.0f;
+            if (in_ranges(skip, nskip, 4 * i + 1)) v.y = 0.0f;
+            if (in_ranges(skip, nskip, 4 * i + 2)) v.z = 0.0f;
+            if (in_ranges(skip, nskip, 4 * i + 3)) v.w = 0.0f;
+        }
         acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = g[(n4 << 2) + threadIdx.x]; acc += t * t; }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long j = (n4 << 2) + threadIdx.x;
+        const float t = (nskip > 0 && in_ranges(skip, nskip, j)) ? 0.0f : g[j];
+        acc += t * t;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -28,9 +51,15 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float4* __restric
 }
 
 extern "C" int mi355_grad_sumsq(const float* grad, int64_t n, float* partials, void* stream) {
+    return mi355_grad_sumsq_masked(grad, n, partials, nullptr, 0, stream);
+}
+
+extern "C" int mi355_grad_sumsq_masked(const float* grad, int64_t n, float* partials, const int64_t* skip_ranges,
+                                       int nskip, void* stream) {
     MI355_REQUIRE(grad && partials && n > 0 && ((uintptr_t)grad & 15) == 0, "grad_sumsq: bad args");
+    MI355_REQUIRE(nskip == 0 || skip_ranges, "grad_sumsq: null skip table");
     hipLaunchKernelGGL(grad_sumsq_kernel, dim3(MI355_OPT_PARTIALS), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)grad, grad, (long long)n, partials);
+                       (const float4*)grad, grad, (long long)n, partials, (const long long*)skip_ranges, nskip);
     return check_launch("grad_sumsq_kernel");
 }
 
@@ -67,7 +96,8 @@ extern "C" int mi355_adamw_prepare(const float* partials, const float* losses, f
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float4* __restrict__ p, float4* __restrict__ g,
                                                          float4* __restrict__ m, float4* __restrict__ v,
                                                          long long n4, float lr, float b1, float b2, float eps,
-                                                         float wd, const OptState* __restrict__ st, int scale_grad) {
+                                                         float wd, const OptState* __restrict__ st, int scale_grad,
+                                                         const long long* __restrict__ skip, int nskip) {
     const OptState s = *st;
     if (s.skip != 0.0f) return;
     const float bc1 = 1.0f - powf(b1, (float)s.step);
@@ -80,6 +110,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float4* __restrict__ p,
         float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+            if (nskip > 0 && in_ranges(skip, nskip, 4 * i + e)) continue;     // untouched, like a `grad is None` parameter
             const float gr = G[e] * c;
             G[e] = gr;
             float x = P[e] * decay;
@@ -96,6 +127,14 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float4* __restrict__ p,
 extern "C" int mi355_adamw_flat(float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, const void* state, int scale_grad,
                                 void* stream) {
+    return mi355_adamw_flat_masked(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, state, scale_grad,
+                                   nullptr, 0, stream);
+}
+
+extern "C" int mi355_adamw_flat_masked(float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                                       float beta2, float eps, float weight_decay, const void* state, int scale_grad,
+                                       const int64_t* skip_ranges, int nskip, void* stream) {
+    MI355_REQUIRE(nskip == 0 || skip_ranges, "adamw_flat: null skip table");
     MI355_REQUIRE(param && grad && m && v && state && n > 0, "adamw_flat: null pointer");
     MI355_REQUIRE((n & 3) == 0, "adamw_flat: arena length must be a multiple of 4 (pad the arena)");
     MI355_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw_flat: alignment");
@@ -104,6 +143,6 @@ extern "C" int mi355_adamw_flat(float* param, float* grad, float* m, float* v, i
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (float4*)param, (float4*)grad, (float4*)m, (float4*)v, n4, lr, beta1, beta2, eps,
-                       weight_decay, (const OptState*)state, scale_grad);
+                       weight_decay, (const OptState*)state, scale_grad, (const long long*)skip_ranges, nskip);
     return check_launch("adamw_flat_kernel");
 }

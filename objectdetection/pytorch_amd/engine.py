@@ -39,6 +39,9 @@ class LayerSpec(object):
         self.Cpad, self.Kpad = _ceil8(self.C), _ceil8(self.K)
         self.T = self.R * self.S
         self.need_dgrad = True
+        # train-mode BatchNorm (batch statistics, optionally synchronised over the replicas): the BN cannot be
+        # folded into the weights; the plan runs conv -> statistics -> normalise (+ residual, ReLU) passes instead
+        self.bn_train = bn is not None and bn.training
         # filled by the plan
         self.w_fwd = self.w_dgr = self.scale = self.shift = None
         self.G = self.colsum = None
@@ -46,8 +49,12 @@ class LayerSpec(object):
         self.direct = False        # wgrad writes straight into the parameter-gradient arena
 
     @property
+    def folded_bn(self):
+        return self.bn if (self.bn is not None and not self.bn_train) else None
+
+    @property
     def bias_tensor(self):
-        return self.shift if self.bn is not None else self.conv.bias
+        return self.shift if self.folded_bn is not None else self.conv.bias
 
     def geometry(self, H, W):
         """-> (pad_top, pad_left, P, Q) for an H x W input."""
@@ -60,10 +67,33 @@ class LayerSpec(object):
         return self.pad, self.pad, P, Q
 
 
+def precision_of(model):
+    """'bf16' (throughput mode: bf16 MFMA operands, fp32 accumulate) or 'fp32' (the reference's own precision,
+    train.py:259-321 runs without autocast: fp32 activations / gradients / shadows on v_mfma_f32_16x16x4_f32).
+    `model.precision` wins over the MI355_CONV_PRECISION environment default."""
+    p = getattr(model, 'precision', None) or os.environ.get('MI355_CONV_PRECISION', 'bf16')
+    if p not in ('bf16', 'fp32'):
+        raise ValueError("precision must be 'bf16' or 'fp32', got %r" % (p,))
+    return p
+
+
+# entry points that have an fp32-mode twin taking the same arguments (include/mi355det_conv.h)
+F32_TWINS = {'mi355_conv_gather': 'mi355_conv_gather_f32', 'mi355_conv_wgrad_slabs': 'mi355_conv_wgrad_slabs_f32',
+             'mi355_maxpool3x3s2_fwd': 'mi355_maxpool3x3s2_fwd_f32', 'mi355_maxpool3x3s2_bwd': 'mi355_maxpool3x3s2_bwd_f32',
+             'mi355_sumpool2x2_bf16': 'mi355_sumpool2x2_f32', 'mi355_relu_mask_bf16': 'mi355_relu_mask_f32'}
+
+
 class RetinaPlan(object):
+    supports_fp32 = True
+
     def __init__(self, model, B, H, W, device):
         self.model, self.B, self.H, self.W, self.dev = model, B, H, W, device
         self.lib = _lib.lib()
+        self.prec = precision_of(model)
+        if self.prec == 'fp32' and not self.supports_fp32:
+            raise _lib.Mi355Error('%s: the fp32-accurate mode is built for the RetinaNet plans only' % type(self).__name__)
+        self.adt = torch.float32 if self.prec == 'fp32' else torch.bfloat16     # activation / gradient storage
+        self.esz = 4 if self.prec == 'fp32' else 2
         self.keep = []                 # ctypes objects referenced by the steps
         self.prep_steps, self.fwd_steps, self.bwd_steps, self.pgrad_steps = [], [], [], []
         self.bufs = []
@@ -72,7 +102,7 @@ class RetinaPlan(object):
         # summed in fixed order by the parameter-gradient table launch: bit-reproducible) or 'atomic'
         # (fp32 atomics straight into the gradient).  MI355_DETERMINISTIC=1 forces 'slabs'.
         self.wgrad_mode = os.environ.get('MI355_WGRAD', 'slabs')
-        if os.environ.get('MI355_DETERMINISTIC', '0') == '1':
+        if os.environ.get('MI355_DETERMINISTIC', '0') == '1' or self.prec == 'fp32':
             self.wgrad_mode = 'slabs'
         assert self.wgrad_mode in ('slabs', 'atomic')
         self.deterministic = self.wgrad_mode == 'slabs'
@@ -80,6 +110,13 @@ class RetinaPlan(object):
         self._side, self._side_dirty = None, False
         self._side_ids, self._mark_side = set(), False
         self.last_arena = 0
+        # one forward, one backward: the activations / assignment state of the LAST forward live in this plan's
+        # buffers; `forward_serial` lets a backward detect that another forward overwrote them (retinanet._TrainStep)
+        self.forward_serial = 0
+        # parameters no launch of this plan reads (BiFPN fusion weights with attention=False): the reference leaves
+        # their .grad None, so autograd gets None and the flat optimizer skips them (train.py:320-321)
+        self.unused_param_ids = set()
+        self.bn_saved = {}
         self._meta()
         if H % self.input_multiple or W % self.input_multiple:
             # the reference's FPN / BiFPN (nn.Upsample x2 + add, retinanet.py:52-61,
@@ -101,8 +138,8 @@ class RetinaPlan(object):
         self.has_maxpool = True
 
     # ------------------------------------------------------------------ bookkeeping
-    def new(self, shape, dtype=torch.bfloat16, zero=False):
-        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
+    def new(self, shape, dtype=None, zero=False):
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype or self.adt, device=self.dev)
         self.bufs.append(t)
         return t
 
@@ -118,11 +155,15 @@ class RetinaPlan(object):
 
     def _step(self, lst, name, *args):
         self.keep.append(args)
+        if self.prec == 'fp32':
+            if name not in F32_TWINS and name.startswith(('mi355_conv_', 'mi355_maxpool', 'mi355_sumpool', 'mi355_relu')):
+                raise _lib.Mi355Error('%s has no fp32-mode twin' % name)
+            name = F32_TWINS.get(name, name)
         lst.append((getattr(self.lib, name), args, name))
         if getattr(self, '_mark_side', False):
             self._side_ids.add(id(args))
 
-    SIDE_STEPS = ('mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum')
+    SIDE_STEPS = ('mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_slabs_f32')
 
     def _run(self, steps, stream):
         """Launch `steps` on `stream`.  With the side stream enabled (MI355_SIDE_STREAM=1) the weight-gradient
@@ -135,6 +176,9 @@ class RetinaPlan(object):
         side = self._side_stream() if (self.use_side and not torch.cuda.is_current_stream_capturing()) else None
         fork = self.lib.mi355_stream_fork
         for fn, args, name in steps:
+            if name.startswith('py:'):                       # host-side step (BN statistics all-reduce), main stream
+                fn(stream)
+                continue
             if side is not None and (name in self.SIDE_STEPS or id(args) in self._side_ids):
                 ss = c_vp(side.cuda_stream)
                 rc = fork(s, ss) or fn(*args, ss)            # side stream ordered behind main's launches so far
@@ -214,8 +258,8 @@ class RetinaPlan(object):
                             for _ in range(2)]
         self.active = 0
         shadow = sum(s.K * s.T * s.Cpad + (s.C * s.T * s.Kpad if s.need_dgrad else 0) for s in self.specs)
-        self.shadow = self.new((shadow + 64,), torch.bfloat16, zero=True)
-        nbn = sum(2 * s.K for s in self.specs if s.bn is not None)
+        self.shadow = self.new((shadow + 64,), self.adt, zero=True)
+        nbn = sum(2 * s.K for s in self.specs if s.folded_bn is not None)
         self.bnbuf = self.new((max(nbn, 1),), torch.float32)
         so, bo = 0, 0
         scratch = 0
@@ -227,7 +271,7 @@ class RetinaPlan(object):
                 n = s.C * s.T * s.Kpad
                 s.w_dgr = self.shadow[so:so + n].view(s.C, s.T, s.Kpad)
                 so += (n + 7) // 8 * 8
-            if s.bn is not None:
+            if s.folded_bn is not None:
                 s.scale = self.bnbuf[bo:bo + s.K]
                 s.shift = self.bnbuf[bo + s.K:bo + 2 * s.K]
                 bo += 2 * s.K
@@ -268,7 +312,8 @@ class RetinaPlan(object):
         d.w = w.data_ptr()
         d.sk, d.sc, d.sr, d.ss = w.stride()
         d.K, d.C, d.R, d.S, d.Cpad, d.Kpad = s.K, s.C, s.R, s.S, s.Cpad, s.Kpad
-        bn = s.bn
+        d.f32_shadows = 1 if self.prec == 'fp32' else 0
+        bn = s.folded_bn                      # (train-mode BN is not folded: plain weights, dW = G)
         if bn is not None:
             d.gamma, d.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
             d.mean, d.var, d.eps = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.eps
@@ -310,7 +355,7 @@ class RetinaPlan(object):
         L.nprob, L.K, L.weight, L.T = len(problems), K, weight.data_ptr(), T
         L.act, L.bias, L.out_f32, L.flags = act, (0 if bias is None else bias.data_ptr()), int(out_f32), flags
         self.keep.append(L)
-        ksplit = self._pick_ksplit(problems, K, T)
+        ksplit = 1 if self.prec == 'fp32' else self._pick_ksplit(problems, K, T)
         if ksplit > 1:
             need = ksplit * sum(p.N * p.P * p.Q for p in problems) * K
             ws = self.new((need,), torch.float32)                 # partial-tile slabs of this launch
@@ -368,6 +413,13 @@ class RetinaPlan(object):
         assert C == spec.Cpad, (spec.name, C, spec.Cpad)
         pt, pl, P, Q = spec.geometry(H, W)
         out = self.new((N, P, Q, spec.Kpad), zero=spec.Kpad != spec.K)
+        if spec.bn_train:
+            # conv -> raw z; batch statistics; y = act(BN(z) + residual).  (K of a BN layer is a multiple of 8.)
+            assert spec.Kpad == spec.K and add_shift == 0, spec.name
+            pr = fwd_problem(x, out.data_ptr(), spec.R, spec.S, spec.stride, (pt, pl), K=spec.K, out_size=(P, Q))
+            self._gather(self.fwd_steps, [pr], spec.w_fwd, spec.K, spec.T, bias=spec.conv.bias)
+            self.fwd_launches.append((spec, [(N, P, Q)]))
+            return self.bn_fwd(spec, spec.bn, out, act, addend)
         pr = fwd_problem(x, out.data_ptr(), spec.R, spec.S, spec.stride, (pt, pl), K=spec.K,
                          addend=addend, add_shift=add_shift, out_size=(P, Q),
                          out_strides=(P * Q * spec.Kpad, Q * spec.Kpad, spec.Kpad))
@@ -375,10 +427,89 @@ class RetinaPlan(object):
         self.fwd_launches.append((spec, [(N, P, Q)]))
         return out
 
+    # ------------------------------------------------------------------ train-mode / synchronised BatchNorm
+    def _pystep(self, lst, fn, name):
+        """A host-side step inside a launch list (the cross-replica all-reduce of BN statistics): called as
+        fn(stream) in list order, on the stream the neighbouring launches use."""
+        def call(stream, fn=fn):
+            fn(stream)
+            return 0
+        lst.append((call, (), name))
+
+    def _bn_sync_group(self, bn):
+        """(synchronise?, process group, replicas): statistics are exchanged for the drop-in
+        SynchronizedBatchNorm2d (utils/sync_batchnorm/batchnorm.py:63-93) when a process group with more than one
+        rank exists; a plain nn.BatchNorm2d in train mode normalises with its replica's own statistics."""
+        import torch.distributed as dist
+        from .utils.sync_batchnorm.batchnorm import SynchronizedBatchNorm2d
+        if isinstance(bn, SynchronizedBatchNorm2d) and dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(bn.group)
+            if world > 1:
+                return True, bn.group, world
+        return False, None, 1
+
+    def _bn_allreduce(self, buf, group):
+        import torch.distributed as dist
+
+        def run(stream, buf=buf, group=group):
+            dist.all_reduce(buf, group=group)       # SUM of [sum | square-sum] (batchnorm.py:118: ReduceAddCoalesced)
+        return run
+
+    def bn_fwd(self, spec, bn, z, act, addend, tag=None):
+        """Batch statistics of z [N,P,Q,C] -> layer state -> y = act(z*scale + shift (+ addend)).  Records what the
+        backward needs under `tag` (default: the spec) in self.bn_saved."""
+        if bn.momentum is None or not bn.affine:
+            raise _lib.Mi355Error('train-mode BN in the launch plan needs affine=True and a float momentum')
+        C = z.shape[-1]
+        M = z.numel() // C
+        nblk, rpb = c_int(), c_int()
+        _lib.call('mi355_bn_nhwc_partial_blocks', c_i64(M), c_int(C), ctypes.byref(nblk), ctypes.byref(rpb))
+        partials = self.new((nblk.value, 2 * C), torch.float32)
+        sums = self.new((2 * C,), torch.float32)
+        state = self.new((5 * C,), torch.float32)
+        sync, group, world = self._bn_sync_group(bn)
+        f32 = c_int(1 if self.prec == 'fp32' else 0)
+        lst = self.fwd_steps
+        self._step(lst, 'mi355_bn_nhwc_stats', ptr(z), c_vp(0), c_vp(0), f32, c_i64(M), c_int(C), c_int(0), ptr(partials))
+        self._step(lst, 'mi355_bn_nhwc_reduce', ptr(partials), c_int(nblk.value), c_int(C), ptr(sums), c_vp(0), c_vp(0))
+        if sync:
+            self._pystep(lst, self._bn_allreduce(sums, group), 'py:bn_allreduce')
+        track = bn.track_running_stats and bn.running_mean is not None
+        plain = type(bn) is torch.nn.BatchNorm2d            # nn.BatchNorm2d.forward counts batches; the sync class does not
+        self._step(lst, 'mi355_bn_nhwc_finalize', ptr(sums), c_f32(float(M) * world), c_int(C), c_f32(bn.eps),
+                   c_f32(bn.momentum), c_int(1 if sync else 0), ptr(bn.weight), ptr(bn.bias),
+                   ptr(bn.running_mean if track else None), ptr(bn.running_var if track else None),
+                   ptr(bn.num_batches_tracked if (track and plain) else None), ptr(state))
+        y = self.new(tuple(z.shape))
+        self._step(lst, 'mi355_bn_nhwc_apply', ptr(z), ptr(state), ptr(addend), c_int(1 if act == ACT_RELU else 0), f32,
+                   c_i64(M), c_int(C), ptr(y))
+        assert act in (ACT_NONE, ACT_RELU)
+        self.bn_saved[id(spec) if tag is None else tag] = (bn, z, state, partials, M, C, sync, group, world)
+        return y
+
+    def bn_bwd(self, spec, g, tag=None):
+        """g = dL/d(BN output, pre-activation) -> dz; dgamma / dbeta (local sums) go straight into the arena."""
+        bn, z, state, partials, M, C, sync, group, world = self.bn_saved[id(spec) if tag is None else tag]
+        arena = getattr(self, '_build_arena', 0)
+        gsums = self.new((2 * C,), torch.float32)
+        f32 = c_int(1 if self.prec == 'fp32' else 0)
+        lst = self.bwd_steps
+        self._step(lst, 'mi355_bn_nhwc_stats', ptr(g), ptr(z), ptr(state), f32, c_i64(M), c_int(C), c_int(1), ptr(partials))
+        self._step(lst, 'mi355_bn_nhwc_reduce', ptr(partials), c_int(partials.shape[0]), c_int(C), ptr(gsums),
+                   ptr(self.grad_view(bn.weight, arena)), ptr(self.grad_view(bn.bias, arena)))
+        if sync:
+            self._pystep(lst, self._bn_allreduce(gsums, group), 'py:bn_allreduce')
+        dz = self.new(tuple(g.shape))
+        self._step(lst, 'mi355_bn_nhwc_bwd_apply', ptr(g), ptr(z), ptr(state), ptr(gsums), c_f32(1.0 / (float(M) * world)),
+                   f32, c_i64(M), c_int(C), ptr(dz))
+        return dz
+
     def conv_bwd(self, spec, x, dy, dx=None, addend=None, mask=None, mask_first=False, dgrad=True):
         """wgrad (+ column sums) of `spec` and, optionally, its data gradient into `dx`."""
         N, H, W, C = x.shape
         pt, pl, P, Q = spec.geometry(H, W)
+        if spec.bn_train:                                  # dy is the gradient of the BN output: through the BN first
+            dy = self.bn_bwd(spec, dy)
         pr = fwd_problem(x, dy.data_ptr(), spec.R, spec.S, spec.stride, (pt, pl), K=spec.Kpad, out_size=(P, Q))
         self._wgrad([pr], spec, N * pr.P * pr.Q)          # + fused column sums (bias / beta grads)
         if not dgrad:
@@ -604,7 +735,7 @@ class RetinaPlan(object):
         gys = self._level_views(gbuf)
         for x, gy, off in zip(xs, gys, self.cell_off):
             h, w = x.shape[1], x.shape[2]
-            dy_ptr = gout.data_ptr() + 2 * off * kp
+            dy_ptr = gout.data_ptr() + self.esz * off * kp
             pr = fwd_problem(x, dy_ptr, 3, 3, 1, 1, K=kp)
             pr.out_sN = self.ncells * kp
             wprobs.append(pr)
@@ -716,12 +847,14 @@ class RetinaPlan(object):
     def run_heads(self, img):
         """prep + forward launches; fills self.cls / self.reg."""
         st = self._stream()
+        self.forward_serial += 1
         img = img.contiguous()
         if img.dtype != torch.float32:
             img = img.float()
         self._img_ref = img
-        rc = self.lib.mi355_nchw_to_nhwc_bf16(ptr(img), ptr(self.img_nhwc), c_int(self.B), c_int(3),
-                                              c_int(self.H), c_int(self.W), c_int(8), c_vp(st))
+        to_nhwc = self.lib.mi355_nchw_to_nhwc_f32 if self.prec == 'fp32' else self.lib.mi355_nchw_to_nhwc_bf16
+        rc = to_nhwc(ptr(img), ptr(self.img_nhwc), c_int(self.B), c_int(3),
+                     c_int(self.H), c_int(self.W), c_int(8), c_vp(st))
         if rc:
             raise _lib.Mi355Error('nchw_to_nhwc: %s' % self.lib.mi355_last_error().decode())
         self._run(self.prep_steps, st)
@@ -755,7 +888,7 @@ class RetinaPlan(object):
         _lib.call('mi355_focal_loss_bwd', ptr(self.cls), ptr(self.reg), ptr(self._anchors), ptr(annot),
                   ptr(self.argmax), ptr(self.state), ptr(self.num_pos), ptr(self.glosses),
                   c_int(self.B), c_int(self.A), c_int(self.num_classes), c_int(annot.shape[1]),
-                  c_f32(ops_detect.ALPHA), c_int(1), ptr(self.gcls), ptr(self.greg),
+                  c_f32(ops_detect.ALPHA), c_int(2 if self.prec == 'fp32' else 1), ptr(self.gcls), ptr(self.greg),
                   c_int(self.A_cell), c_int(self.cls_pitch), c_int(self.reg_pitch), c_vp(st))
         self._bwd_pos = 0
         return arena
@@ -798,7 +931,21 @@ class RetinaPlan(object):
         self._extra_param_grads(arena, st)
         if not want_views:
             return None
-        return [self.grad_view(p, arena) if p.requires_grad else None for p in self.params]
+        return [self.grad_view(p, arena) if (p.requires_grad and id(p) not in self.unused_param_ids) else None
+                for p in self.params]
+
+    def skip_ranges(self):
+        """Sorted, merged arena ranges [lo, hi) of the parameters torch's clip_grad_norm_ / AdamW would skip
+        (`grad is None`): requires_grad == False or unused by this plan."""
+        out = []
+        for p in self.params:
+            if not p.requires_grad or id(p) in self.unused_param_ids:
+                lo = self.grad_offsets[id(p)]
+                if out and out[-1][1] == lo:
+                    out[-1][1] = lo + p.numel()
+                else:
+                    out.append([lo, lo + p.numel()])
+        return [tuple(r) for r in out]
 
     def _zero_extra(self):
         pass
@@ -823,7 +970,9 @@ class RetinaPlan(object):
         main_steps, main_keep = self.bwd_steps, self.keep
         self.bwd_steps = []
         self._carve_grads(1)
+        self._build_arena = 1                      # (train-mode BN: dgamma / dbeta pointers of the alternate arena)
         self._build_backward()
+        self._build_arena = 0
         self.bwd_steps_alt = self.bwd_steps
         self.bwd_steps = main_steps
         self._carve_grads(0)

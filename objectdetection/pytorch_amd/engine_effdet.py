@@ -67,6 +67,7 @@ class SeSpec(object):
 
 
 class EffDetPlan(RetinaPlan):
+    supports_fp32 = False          # (depthwise / SE / BiFPN kernels store bf16)
     # ------------------------------------------------------------------ meta / layers
     def _meta(self):
         self.num_classes = self.model.num_classes
@@ -477,6 +478,10 @@ class EffDetPlan(RetinaPlan):
 
         def fw(name):
             return getattr(cell, name) if att else None
+        if not att:                 # efficientdet.py:269-317: the plain-sum path never touches the fusion parameters
+            for n in ('p6_w1', 'p5_w1', 'p4_w1', 'p3_w1', 'p4_w2', 'p5_w2', 'p6_w2', 'p7_w2'):
+                if hasattr(cell, n):
+                    self.unused_param_ids.add(id(getattr(cell, n)))
         p6_up = self.sep_op(rec['conv6_up'], self.node_op(fw('p6_w1'), p6_in, p7_in, True))
         p5_up = self.sep_op(rec['conv5_up'], self.node_op(fw('p5_w1'), p5_in, p6_up, True))
         p4_up = self.sep_op(rec['conv4_up'], self.node_op(fw('p4_w1'), p4_in, p5_up, True))

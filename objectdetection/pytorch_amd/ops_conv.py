@@ -36,6 +36,7 @@ class LayerDesc(ctypes.Structure):
     _fields_ = [('w', c_vp), ('sk', c_i64), ('sc', c_i64), ('sr', c_i64), ('ss', c_i64),
                 ('K', c_int), ('C', c_int), ('R', c_int), ('S', c_int), ('Cpad', c_int), ('Kpad', c_int),
                 ('block_begin', c_int), ('eps', c_f32), ('atomic', c_int), ('nslabs', c_int),
+                ('f32_shadows', c_int), ('reserved', c_int),
                 ('gamma', c_vp), ('beta', c_vp), ('mean', c_vp), ('var', c_vp), ('conv_bias', c_vp),
                 ('scale', c_vp), ('shift', c_vp), ('w_fwd', c_vp), ('w_dgr', c_vp),
                 ('G', c_vp), ('colsum', c_vp), ('dW', c_vp), ('dgamma', c_vp), ('dbeta', c_vp),
@@ -112,12 +113,13 @@ def dgrad_problems(dy, dx_ptr, H, W, Cin, R, S, stride, pad, addend=None, mask=N
             if addend is not None:      # addend indexed on the dx grid (h, w) = (p*stride+ph, ...)
                 pr.add_sN = addend.stride(0)
                 pr.add_sH, pr.add_sW = addend.stride(1) * stride, addend.stride(2) * stride
-                pr.addend = addend.data_ptr() + 2 * (ph * addend.stride(1) + pw * addend.stride(2))
+                pr.addend = addend.data_ptr() + addend.element_size() * (ph * addend.stride(1) + pw * addend.stride(2))
             probs.append(pr)
     return probs
 
 
 def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE, out_f32=False, ksplit=1):
+    f32 = weight.dtype == torch.float32            # fp32-accurate mode: every operand fp32 (conv_f32.hip)
     for i in range(0, len(problems), MAX_PROBLEMS):
         chunk = problems[i:i + MAX_PROBLEMS]
         L = ConvLaunch()
@@ -125,7 +127,9 @@ def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE
             L.prob[j] = pr
         L.nprob, L.K, L.weight, L.T = len(chunk), K, weight.data_ptr(), T
         L.act, L.bias, L.out_f32 = act, _dp(bias), 1 if out_f32 else 0
-        if ksplit > 1:      # reduction split over blocks, partial tiles in a scratch workspace
+        if f32:
+            call('mi355_conv_gather_f32', ctypes.byref(L), stream_of(stream_tensor))
+        elif ksplit > 1:      # reduction split over blocks, partial tiles in a scratch workspace
             ws = torch.empty(ksplit * sum(p.N * p.P * p.Q for p in chunk) * K, dtype=torch.float32,
                              device=stream_tensor.device)
             call('mi355_conv_gather_splitk', ctypes.byref(L), c_int(ksplit), ptr(ws), stream_of(stream_tensor))
@@ -133,11 +137,15 @@ def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE
             call('mi355_conv_gather', ctypes.byref(L), stream_of(stream_tensor))
 
 
-def launch_wgrad(problems, K, T, dw, split_rows, stream_tensor, colsum=None):
+def launch_wgrad(problems, K, T, dw, split_rows, stream_tensor, colsum=None, f32=False):
     L = ConvLaunch()
     for j, pr in enumerate(problems):
         L.prob[j] = pr
     L.nprob, L.K, L.T = len(problems), K, T
+    if f32:                                        # fp32-accurate mode (atomic form: slab stride 0)
+        call('mi355_conv_wgrad_slabs_f32', ctypes.byref(L), ptr(dw), c_i64(0), c_int(0), ptr(colsum),
+             c_int(split_rows), stream_of(stream_tensor))
+        return
     call('mi355_conv_wgrad_colsum', ctypes.byref(L), ptr(dw), ptr(colsum), c_int(split_rows),
          stream_of(stream_tensor))
 
@@ -182,7 +190,8 @@ def conv_fwd(x, w_fwd, K, R, S, stride, pad, bias=None, act=ACT_NONE, addend=Non
     require_gpu(x, w_fwd)
     N, H, W, C = x.shape
     P, Q = out_hw(H, W, R, stride, pad)[0], out_hw(H, W, S, stride, pad)[1]
-    out = torch.empty((N, P, Q, K), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    out = torch.empty((N, P, Q, K), dtype=torch.float32 if (out_f32 or x.dtype == torch.float32) else torch.bfloat16,
+                      device=x.device)
     pr = fwd_problem(x, out.data_ptr(), R, S, stride, pad, K=K, addend=addend, add_shift=add_shift)
     launch_gather([pr], w_fwd, K, R * S, x, bias=bias, act=act, out_f32=out_f32, ksplit=ksplit)
     return out
@@ -191,7 +200,7 @@ def conv_fwd(x, w_fwd, K, R, S, stride, pad, bias=None, act=ACT_NONE, addend=Non
 def conv_dgrad(dy, w_dgr, H, W, Cin, R, S, stride, pad, addend=None, mask=None):
     require_gpu(dy, w_dgr)
     N = dy.shape[0]
-    dx = torch.empty((N, H, W, Cin), dtype=torch.bfloat16, device=dy.device)
+    dx = torch.empty((N, H, W, Cin), dtype=dy.dtype, device=dy.device)
     probs = dgrad_problems(dy, dx.data_ptr(), H, W, Cin, R, S, stride, pad, addend=addend, mask=mask)
     launch_gather(probs, w_dgr, Cin, R * S, dy)
     return dx
@@ -209,7 +218,7 @@ def conv_wgrad(x, dy, R, S, stride, pad, split_rows=None, out=None, colsum=None)
     M = N * pr.P * pr.Q
     if split_rows is None:
         split_rows = pick_split_rows(M, wgrad_tiles(Kp, C, T))
-    launch_wgrad([pr], Kp, T, out, split_rows, x, colsum=colsum)
+    launch_wgrad([pr], Kp, T, out, split_rows, x, colsum=colsum, f32=x.dtype == torch.float32)
     return out
 
 

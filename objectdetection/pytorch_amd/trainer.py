@@ -188,15 +188,29 @@ class Trainer(object):
         g2.replay()
         return self._g_losses
 
+    def _skip_table(self, plan):
+        """Device table of the arena ranges the reference's clip + AdamW never touch (`p.grad is None`): frozen
+        (requires_grad == False, the commented head-only fine-tune of train.py:206-216) and unused parameters
+        (BiFPN fusion weights of D6/D7).  Rebuilt when a requires_grad flag flips."""
+        sig = (id(plan), tuple(p.requires_grad for p in self.params))
+        if getattr(self, '_skip_sig', None) != sig:
+            rs = plan.skip_ranges()
+            self._skip = (torch.tensor(rs, dtype=torch.int64, device=self.flat.device).reshape(-1) if rs else None,
+                          len(rs))
+            self._skip_sig = sig
+        return self._skip
+
     def _update(self, plan, loss_flag):
         grad = plan.grad_arenas[plan.last_arena]
         s = c_vp(torch.cuda.current_stream(grad.device).cuda_stream)
-        self._call('mi355_grad_sumsq', ptr(grad), c_i64(plan.grad_numel_padded), ptr(self.partials), s)
+        skip, nskip = self._skip_table(plan)
+        self._call('mi355_grad_sumsq_masked', ptr(grad), c_i64(plan.grad_numel_padded), ptr(self.partials),
+                   ptr(skip), c_int(nskip), s)
         self._call('mi355_adamw_prepare', ptr(self.partials), ptr(loss_flag), c_f32(self.clip_norm),
                    ptr(self.state), s)
-        self._call('mi355_adamw_flat', ptr(self.flat), ptr(grad), ptr(self.m), ptr(self.v),
+        self._call('mi355_adamw_flat_masked', ptr(self.flat), ptr(grad), ptr(self.m), ptr(self.v),
                    c_i64(self.npad), c_f32(self.lr), c_f32(self.betas[0]), c_f32(self.betas[1]),
-                   c_f32(self.eps), c_f32(self.wd), ptr(self.state), c_int(1), s)
+                   c_f32(self.eps), c_f32(self.wd), ptr(self.state), c_int(1), ptr(skip), c_int(nskip), s)
 
     def _call(self, name, *args):
         rc = getattr(self.lib, name)(*args)

@@ -51,13 +51,21 @@ def test_effdet_vs_reference_golden(golden_dir, tag):
     model.zero_grad()
     (cl.mean() + rl.mean()).backward()
     grads = dict((k, p.grad) for k, p in model.named_parameters())
-    assert all(v is not None for v in grads.values())
-    gn = np.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values()))
+    # D6 / D7 run the plain-sum BiFPN (efficientdet.py:269-317): the fusion parameters feed nothing and the
+    # reference leaves their .grad None (so clip_grad_norm_ / AdamW skip them, train.py:320-321)
+    import re
+    unused = set(k for k in grads if re.search(r'\.p\d_w[12]$', k)) if coef >= 6 else set()
+    assert all((v is None) == (k in unused) for k, v in grads.items()), [k for k, v in grads.items() if v is None]
+    assert coef < 6 or len(unused) > 0
+    gn = np.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values() if v is not None))
     np.testing.assert_allclose(gn, float(g['grad_global_norm']), rtol=6e-2)
     worst = 1.0
     for key in g.files:
         if key.startswith('grad/') and key.endswith('/val'):
             name = key[5:-4]
+            if name in unused:
+                assert np.linalg.norm(g[key]) == 0.0
+                continue
             sel = torch.from_numpy(g['grad/%s/idx' % name]).to(DEV)
             got = grads[name].reshape(-1)[sel].cpu().numpy()
             ref = g[key]

@@ -1,0 +1,158 @@
+"""End-to-end parity of the fp32-accurate execution mode (`model.precision = 'fp32'` /
+MI355_CONV_PRECISION=fp32: fp32 activations, gradients and weight shadows on v_mfma_f32_16x16x4_f32,
+csrc/conv_f32.hip) against the golden vectors produced by the reference itself (fp32 CPU,
+tools/make_golden.py).  This is the mode held to the north-star bound: both losses within 1e-4 relative,
+every sampled parameter-gradient tensor within 1e-3 relative L2, head tensors within 1e-4 of their range.
+(The bf16 throughput mode is checked against the same goldens at bf16 tolerances in test_gpu_retinanet.py.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-4          # BASELINE.json north_star: "fp32 losses and box regressions within 1e-4 relative"
+GRAD_REL_L2 = 1e-3
+HEAD_TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda', 0)
+
+
+def _rel(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)
+
+
+def _check_grads(g, grads, dev):
+    """Per sampled tensor: `grad/*` = the reference's fp32 run, `grad64/*` = the same reference model run in
+    float64 (tools/make_golden.py:_add_fp64_run).  Backbone gradients are ill-conditioned sums with ReLU-mask
+    flips: the reference's OWN fp32 run sits 3e-4 .. 3e-3 relative L2 from its fp64 value (conv1.weight, 32 768
+    random-sign terms per element, is the worst), so two correct fp32 evaluations cannot agree to 1e-3 there.
+    fp32 evaluation order also moves single ReLU-mask / smooth-L1-kink decisions in the heads: torch's own two CPU
+    conv algorithms (oneDNN vs native, tools/fp32_noise_floor.py) disagree by 5.5e-4 on regressionModel.conv1-3.weight
+    and 1e-4 on the class tower with THIS input, each being 1e-6 from fp64 on the tensors the other one misses.
+    Bounds: vs the fp32 golden 1e-3, or 3x the reference's own fp32 noise where that is larger; vs the exact
+    (fp64) value 1e-3, or 2x the reference's own fp32 distance from it where that is larger."""
+    worst, rows = ('', 0.0), []
+    for key in g.files:
+        if key.startswith('grad/') and key.endswith('/val'):
+            name = key[5:-4]
+            sel = torch.from_numpy(g['grad/%s/idx' % name]).to(dev)
+            got = grads[name].reshape(-1)[sel].cpu().numpy().astype(np.float64)
+            ref = g[key].astype(np.float64)
+            ref64 = g['grad64/%s/val' % name].astype(np.float64)
+            if np.linalg.norm(ref64) < 1e-12:
+                assert np.linalg.norm(got) < 1e-6, name
+                continue
+            n64 = np.linalg.norm(ref64)
+            noise = float(np.linalg.norm(ref - ref64) / n64)           # the reference's own fp32 error
+            e32 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            e64 = float(np.linalg.norm(got - ref64) / n64)
+            rows.append((name, noise, e32, e64))
+            if e32 > worst[1]:
+                worst = (name, e32)
+    for r in rows:
+        print('  %-44s reference fp32-vs-fp64 %.2e | ours vs fp32 golden %.2e | ours vs fp64 %.2e' % r)
+    for name, noise, e32, e64 in rows:
+        assert e32 <= max(GRAD_REL_L2, 3.0 * noise), (name, e32, noise)
+        assert e64 <= max(GRAD_REL_L2, 2.0 * noise), (name, e64, noise)
+    return worst
+
+
+@pytest.mark.parametrize('tag', ['r18_256', 'r50_128x160'])
+def test_fp32_mode_vs_reference_golden(golden_dir, dev, tag):
+    from objectdetection.pytorch_amd.architectures import retinanet
+    g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
+    depth, (H, W), B, nc = int(g['depth']), g['hw'], int(g['batch']), int(g['num_classes'])
+    model = retinanet.retinanet(depth, num_classes=nc)
+    model.precision = 'fp32'
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=float(g['gain']))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    model.train()
+    model.freeze_bn()
+    img = torch.from_numpy(synth.synth_images(B, int(H), int(W), seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(B, int(H), int(W), 8, 16, nc, seed=2)).to(dev)
+    cls, reg = model(img, return_head=True)
+    idx = g['head_idx']
+    assert _rel(reg.cpu().numpy()[:, idx], g['reg_rows']) < HEAD_TOL
+    assert _rel(cls.cpu().numpy()[:, idx], g['cls_rows']) < HEAD_TOL
+    cl, rl = model(img, ann)
+    np.testing.assert_allclose(cl.item(), g['cls_loss'].item(), rtol=LOSS_RTOL)
+    np.testing.assert_allclose(rl.item(), g['reg_loss'].item(), rtol=LOSS_RTOL)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()                     # train.py:312-319
+    grads = dict((k, p.grad) for k, p in model.named_parameters())
+    gn = np.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values()))
+    np.testing.assert_allclose(gn, float(g['grad_global_norm']), rtol=1e-4)
+    worst = _check_grads(g, grads, dev)
+    print('fp32 mode %s: cls %.7g (ref %.7g) reg %.7g (ref %.7g) worst sampled-grad relL2 %s %.3g'
+          % (tag, cl.item(), g['cls_loss'].item(), rl.item(), g['reg_loss'].item(), worst[0], worst[1]))
+    # the plan is keyed by precision: the same model object in bf16 mode builds its own plan
+    model.precision = 'bf16'
+    cl16, _ = model(img, ann)
+    assert len(model._plans) == 2
+    np.testing.assert_allclose(cl16.item(), g['cls_loss'].item(), rtol=3e-2)
+
+
+@pytest.mark.parametrize('tag', ['tiny_64x96', 'p45p6_192x288'])
+def test_fp32_mode_three_level_variants(golden_dir, dev, tag):
+    from objectdetection.pytorch_amd.architectures import retinanet
+    g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
+    kind, (H, W), B, nc = str(g['kind']), g['hw'], int(g['batch']), int(g['num_classes'])
+    model = {'tiny': retinanet.retinanet_tiny, 'p45p6': retinanet.retinanet_p45p6}[kind](nc)
+    model.precision = 'fp32'
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=float(g['gain']))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    model.train()
+    model.freeze_bn()
+    img = torch.from_numpy(synth.synth_images(B, int(H), int(W), seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(B, int(H), int(W), 8, 16, nc, seed=2)).to(dev)
+    cl, rl = model((img, ann)) if kind == 'tiny' else model(img, ann)
+    np.testing.assert_allclose(cl.item(), g['cls_loss'].item(), rtol=LOSS_RTOL)
+    np.testing.assert_allclose(rl.item(), g['reg_loss'].item(), rtol=LOSS_RTOL)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = dict((k, p.grad) for k, p in model.named_parameters())
+    gn = np.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values()))
+    np.testing.assert_allclose(gn, float(g['grad_global_norm']), rtol=1e-4)
+    _check_grads(g, grads, dev)
+    model.eval()
+    s, c, b = model(img[:1]) if kind == 'tiny' else model(img[:1], return_loss=False)
+    ref_s = g['det_scores']
+    assert s.numel() == len(ref_s)                         # fp32 scores: the same detections survive
+    np.testing.assert_allclose(s.cpu().numpy(), ref_s, rtol=1e-4, atol=1e-6)
+
+
+def test_fp32_trainer_step_matches_torch_adamw(golden_dir, dev):
+    """The flat-arena Trainer drives the fp32 plan as well (same arenas, same three optimizer launches)."""
+    from objectdetection.pytorch_amd.architectures import retinanet
+    from objectdetection.pytorch_amd.trainer import Trainer
+    g = np.load(os.path.join(golden_dir, 'e2e_r18_256.npz'))
+    nc = int(g['num_classes'])
+    model = retinanet.retinanet(18, num_classes=nc)
+    model.precision = 'fp32'
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=float(g['gain']))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    model.train()
+    model.freeze_bn()
+    img = torch.from_numpy(synth.synth_images(2, 256, 256, seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(2, 256, 256, 8, 16, nc, seed=2)).to(dev)
+    tr = Trainer(model)
+    losses = tr.step(img, ann)
+    np.testing.assert_allclose(losses[0].item(), g['cls_loss'].item(), rtol=LOSS_RTOL)
+    np.testing.assert_allclose(losses[1].item(), g['reg_loss'].item(), rtol=LOSS_RTOL)
+    l2 = tr.step(img, ann)
+    assert torch.isfinite(l2).all() and tr.step_count == 2

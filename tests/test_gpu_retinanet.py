@@ -80,25 +80,53 @@ def test_heads_losses_grads_vs_reference_golden(golden_dir, dev, tag):
     print('worst sampled-grad cosine', worst)
 
 
-def test_vs_oracle_same_bf16_rounded_weights(golden_dir, dev):
-    """Tighter check: the oracle run with bf16-ROUNDED weights and input removes the weight-
-    quantisation term, leaving only activation rounding + accumulation order."""
-    g, model, img, ann, sd = _build('r18_256', golden_dir, dev)
-    p = {}
-    for k, v in sd.items():
-        t = torch.from_numpy(v)
-        p[k] = t
-    cls, reg = model(img, return_head=True)
+# per-tensor relative-L2 bound of the bf16 plan against its CPU twin (`emulate_bf16=True`: weights rounded after
+# the frozen-BN fold, input / every stored activation / every stored activation-gradient rounded to bf16, fp32
+# accumulation).  What is left between the two is accumulation order plus the ReLU-mask / max-pool-argmax flips
+# that order causes; bounds = 2x the spread measured on MI355X (printed by the test).  conv1.weight is the
+# ill-conditioned one: each element sums ~32 768 random-sign terms (the reference's own fp32 run is 3.3e-3 from
+# its fp64 value there, 10x its other backbone tensors: tests/golden `grad64/*`), so bf16 noise shows 10x as well.
+TWIN_REL_L2 = {'r18_256': 0.12, 'r50_128x160': 0.20}
+TWIN_REL_L2_STEM = 0.5
+
+
+@pytest.mark.parametrize('tag', ['r18_256', 'r50_128x160'])
+def test_vs_oracle_same_bf16_rounded_weights(golden_dir, dev, tag):
+    """The bf16 mode against the oracle run as its numerical twin (same rounding points, fp32 accumulate):
+    heads and losses at 1e-2 (the fp32 reference only allows 3e-2), every sampled parameter gradient by
+    relative L2 (not a cosine gate: a wrong tap or a dropped term in a small layer shows up here)."""
+    g, model, img, ann, sd = _build(tag, golden_dir, dev)
+    depth = int(g['depth'])
+    p = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype == np.float32 and 'running' not in k)
+         for k, v in sd.items()}
+    cl_o, rl_o = ref_cpu.retinanet_loss(p, img.cpu(), ann.cpu(), depth, emulate_bf16=True)
+    (cl_o.mean() + rl_o.mean()).backward()
     with torch.no_grad():
-        cls_o, reg_o = ref_cpu.retinanet_heads(p, img.cpu(), 18)
-    assert _rel(reg.cpu().numpy(), reg_o.numpy()) < 3e-2
-    assert _rel(cls.cpu().numpy(), cls_o.numpy()) < 3e-2
-    # loss on the DEVICE head tensors, oracle arithmetic: isolates the fused loss at full size
-    anchors = torch.from_numpy(ref_cpu.anchors_for_image(256, 256))
-    cl_o, rl_o = ref_cpu.focal_loss(cls.cpu(), reg.cpu(), anchors, ann.cpu())
+        cls_o, reg_o = ref_cpu.retinanet_heads(p, img.cpu(), depth, emulate_bf16=True)
+    cls, reg = model(img, return_head=True)
+    assert _rel(reg.cpu().numpy(), reg_o.numpy()) < 1e-2
+    assert _rel(cls.cpu().numpy(), cls_o.numpy()) < 1e-2
     cl, rl = model(img, ann)
-    np.testing.assert_allclose(cl.item(), cl_o.item(), rtol=1e-4)     # north_star tolerance
-    np.testing.assert_allclose(rl.item(), rl_o.item(), rtol=1e-4)
+    np.testing.assert_allclose(cl.item(), cl_o.item(), rtol=1e-2)
+    np.testing.assert_allclose(rl.item(), rl_o.item(), rtol=1e-2)
+    # loss on the DEVICE head tensors, oracle arithmetic: isolates the fused loss at full size
+    anchors = torch.from_numpy(ref_cpu.anchors_for_image(img.shape[2], img.shape[3]))
+    cl_e, rl_e = ref_cpu.focal_loss(cls.cpu(), reg.cpu(), anchors, ann.cpu())
+    np.testing.assert_allclose(cl.item(), cl_e.item(), rtol=1e-4)     # north_star tolerance
+    np.testing.assert_allclose(rl.item(), rl_e.item(), rtol=1e-4)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    rows = []
+    for name, prm in model.named_parameters():
+        got = prm.grad.detach().cpu().double().reshape(-1)
+        ref = p[name].grad.double().reshape(-1)
+        if float(ref.norm()) < 1e-12:
+            continue
+        rows.append((float((got - ref).norm() / ref.norm()), name))
+    rows.sort(reverse=True)
+    print('bf16 plan vs bf16 twin, %s: worst per-tensor relL2 %s' % (tag, ['%s %.3f' % (n, r) for r, n in rows[:6]]))
+    for r, name in rows:
+        assert r <= (TWIN_REL_L2_STEM if name == 'conv1.weight' else TWIN_REL_L2[tag]), (name, r)
 
 
 def test_decode_tail_vs_golden(golden_dir, dev):

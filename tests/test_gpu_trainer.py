@@ -210,3 +210,105 @@ def test_overlapped_dp_exchange_two_ranks():
     assert np.array_equal(r0['single']['flat'], r0['overlap']['flat'])
     assert np.array_equal(r0['single']['flat'], r0['overlap_graph']['flat'])
     assert not np.array_equal(r0['single']['loss'], r1['single']['loss'])    # different shards
+
+
+def test_flat_adamw_masked_skips_like_grad_none():
+    """Parameters whose .grad is None are skipped by torch's clip_grad_norm_ and AdamW (no norm contribution,
+    no weight decay, no moments): the masked passes with arena skip ranges do the same."""
+    from objectdetection.pytorch_amd import _lib
+    from objectdetection.pytorch_amd._lib import c_f32, c_i64, c_int, c_vp, ptr
+    dev = torch.device('cuda', 0)
+    sizes = [1000, 7, 4099, 64, 13, 50000]
+    frozen = {1, 3, 4}                                       # two adjacent -> merged range, unaligned bounds
+    g = torch.Generator(device='cpu').manual_seed(5)
+    n = sum(sizes)
+    npad = (n + 3) // 4 * 4
+    p0 = torch.randn(npad, generator=g).to(dev)
+    offs = np.cumsum([0] + sizes)
+    refs = [torch.nn.Parameter(p0[offs[i]:offs[i + 1]].clone()) for i in range(len(sizes))]
+    opt = torch.optim.AdamW(refs, lr=1e-3, weight_decay=5e-2)
+    flat, m, v = p0.clone(), torch.zeros(npad, device=dev), torch.zeros(npad, device=dev)
+    state = torch.zeros(4, dtype=torch.int32, device=dev)
+    partials = torch.zeros(1024, device=dev)
+    ranges, cur = [], None
+    for i in range(len(sizes)):
+        if i in frozen:
+            if cur is not None and cur[1] == offs[i]:
+                cur[1] = int(offs[i + 1])
+            else:
+                cur = [int(offs[i]), int(offs[i + 1])]
+                ranges.append(cur)
+    skip = torch.tensor(ranges, dtype=torch.int64, device=dev).reshape(-1)
+    st = c_vp(torch.cuda.current_stream().cuda_stream)
+    for it in range(3):
+        grad = (torch.randn(npad, generator=g) * (0.0005 if it == 1 else 3.0)).to(dev)
+        grad[n:] = 0
+        for i, r in enumerate(refs):
+            r.grad = None if i in frozen else grad[offs[i]:offs[i + 1]].clone()
+        total = torch.nn.utils.clip_grad_norm_(refs, 0.1)
+        opt.step()
+        mine = grad.clone()                                   # frozen ranges hold garbage gradients: must be ignored
+        _lib.call('mi355_grad_sumsq_masked', ptr(mine), c_i64(npad), ptr(partials), ptr(skip), c_int(len(ranges)), st)
+        _lib.call('mi355_adamw_prepare', ptr(partials), c_vp(0), c_f32(0.1), ptr(state), st)
+        _lib.call('mi355_adamw_flat_masked', ptr(flat), ptr(mine), ptr(m), ptr(v), c_i64(npad), c_f32(1e-3),
+                  c_f32(0.9), c_f32(0.999), c_f32(1e-8), c_f32(5e-2), ptr(state), c_int(1), ptr(skip),
+                  c_int(len(ranges)), st)
+        np.testing.assert_allclose(state.view(torch.float32)[3].item(), float(total), rtol=1e-5)
+    for i, r in enumerate(refs):
+        got = flat[offs[i]:offs[i + 1]]
+        if i in frozen:
+            assert torch.equal(got, p0[offs[i]:offs[i + 1]])          # bit-identical: never touched
+            assert float(m[offs[i]:offs[i + 1]].abs().max()) == 0.0
+        else:
+            np.testing.assert_allclose(got.cpu().numpy(), r.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+
+
+def test_trainer_leaves_frozen_parameters_alone():
+    """requires_grad=False parameters (the head-only fine-tune of train.py:206-216) are skipped by torch's
+    clip + AdamW; the flat trainer must neither decay nor move them, and must not count them in the norm."""
+    from objectdetection.pytorch_amd.trainer import Trainer
+    dev = torch.device('cuda', 0)
+    img = torch.from_numpy(synth.synth_images(2, 128, 128, seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(2, 128, 128, 6, 8, 8, seed=2)).to(dev)
+    mine = _model(dev)
+    for k, p in mine.named_parameters():
+        if not (k.startswith('regressionModel') or k.startswith('classificationModel')):
+            p.requires_grad = False
+    before = {k: p.detach().clone() for k, p in mine.named_parameters()}
+    tr = Trainer(mine)
+    for _ in range(2):
+        tr.step(img, ann)
+    plan = mine._plans[next(iter(mine._plans))]
+    assert len(plan.skip_ranges()) == 1                       # backbone + pyramid: one merged range
+    moved = 0
+    for k, p in mine.named_parameters():
+        if p.requires_grad:
+            moved += int((p.detach() != before[k]).any())
+        else:
+            assert torch.equal(p.detach(), before[k]), k
+    assert moved > 0
+    # the clip norm is the norm of the trainable gradients only
+    arena = plan.grad_arenas[plan.last_arena]
+    lo, hi = plan.skip_ranges()[0]
+    live = torch.cat([arena[:lo], arena[hi:]])
+    assert float(torch.linalg.vector_norm(live)) <= 0.1 * 1.001
+
+
+def test_backward_after_second_forward_raises():
+    """The launch plan keeps ONE set of activations per input shape: a forward between a loss and its
+    backward (validation call, return_head, second micro-batch) must raise instead of silently returning
+    the gradients of the wrong batch."""
+    dev = torch.device('cuda', 0)
+    model = _model(dev)
+    img = torch.from_numpy(synth.synth_images(2, 64, 64, seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(2, 64, 64, 4, 8, 8, seed=2)).to(dev)
+    cl, rl = model(img, ann)
+    model(img, return_head=True)
+    with pytest.raises(RuntimeError, match='another forward'):
+        (cl + rl).sum().backward()
+    cl, rl = model(img, ann)                                  # a fresh forward/backward pair still works
+    (cl + rl).sum().backward()
+    other = torch.from_numpy(synth.synth_images(2, 96, 64, seed=3)).to(dev)
+    cl, rl = model(img, ann)
+    model(other, return_head=True)                            # another SHAPE has its own plan: fine
+    (cl + rl).sum().backward()

@@ -306,6 +306,24 @@ GRAD_KEYS = ['conv1.weight', 'bn1.weight', 'bn1.bias', 'layer1.0.conv1.weight',
              'classificationModel.output.weight', 'classificationModel.output.bias']
 
 
+def _add_fp64_run(d, model, img_t, ann_t, call, keys):
+    """The SAME reference model evaluated in float64 (`model.double()`): the exact value of the arithmetic the
+    fp32 reference run approximates.  Some parameter gradients are ill-conditioned sums (conv1.weight: 32 768
+    random-sign terms per element), so the reference's own fp32 run is 1e-3 .. 3e-3 relative L2 away from it;
+    `grad64/*` lets the fp32-mode parity test measure an implementation against the exact value with the
+    reference's own fp32 noise (`grad/*` vs `grad64/*`) as the yardstick."""
+    model.double()
+    model.zero_grad()
+    cl, rl = call(model, img_t.double(), ann_t.double())
+    (cl.mean() + rl.mean()).backward()
+    g64 = {k: p.grad.numpy().copy() for k, p in model.named_parameters()}
+    d['cls_loss64'], d['reg_loss64'] = cl.detach().numpy(), rl.detach().numpy()
+    for k in keys:
+        d['grad64/' + k + '/val'] = g64[k].reshape(-1)[d['grad/' + k + '/idx']]
+    d['grad_global_norm64'] = np.array(np.sqrt(sum((g ** 2).sum() for g in g64.values())))
+    model.zero_grad()
+
+
 def gen_e2e(depth, H, W, B, num_classes, tag, gain):
     torch.manual_seed(0)
     model = ref_retinanet.retinanet(depth, num_classes=num_classes)
@@ -343,6 +361,8 @@ def gen_e2e(depth, H, W, B, num_classes, tag, gain):
                                                  for g in grads.values())))
     d['state_keys'] = np.array(list(shapes.keys()))
     d['state_shapes'] = np.array([','.join(map(str, shapes[k])) for k in shapes])
+    _add_fp64_run(d, model, img_t, ann_t, lambda m, i, a: m(i, a), [k for k in GRAD_KEYS if k in grads])
+    model.float()
     # decode tail on image 0 (B must be 1, retinanet.py:302)
     model.eval()
     with torch.no_grad():
@@ -386,6 +406,9 @@ def gen_e2e_variant(kind, H, W, B, num_classes, tag, gain):
     d['grad_global_norm'] = np.array(np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in grads.values())))
     d['state_keys'] = np.array(list(shapes.keys()))
     d['state_shapes'] = np.array([','.join(map(str, shapes[k])) for k in shapes])
+    _add_fp64_run(d, model, img_t, ann_t, (lambda m, i, a: m((i, a))) if kind == 'tiny' else (lambda m, i, a: m(i, a)),
+                  [k[5:-4] for k in list(d) if k.startswith('grad/') and k.endswith('/val')])
+    model.float()
     d['anchors'] = model.anchors(img_t).numpy()
     model.eval()
     with torch.no_grad():
