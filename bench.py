@@ -39,6 +39,7 @@ import torch.distributed as dist   # noqa: E402
 import synth                # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparse figure)
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s is what a float4 copy reaches)
 
 
 def parse():
@@ -52,6 +53,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-infer', action='store_true', help='skip the `infer` sub-object (batched heads, B=1 decode)')
     ap.add_argument('--graph', type=int, default=int(os.environ.get('MI355_GRAPH', '0')),
                     help='replay the step from captured hipGraphs (default off: the step is GPU-bound and the '
                          'two-stream schedule runs faster launched eagerly than as a branched graph)')
@@ -141,6 +143,52 @@ def conv_bytes(plan):
     return total
 
 
+def conv_launch_bytes(L, name):
+    """One conv launch of `conv_bytes`: every operand read once, every result written once."""
+    gather = name.startswith('mi355_conv_gather')
+    total = 2.0 * L.K * L.T * L.prob[0].C * (1 if gather else 2)
+    for i in range(L.nprob):
+        p = L.prob[i]
+        M = p.N * p.P * p.Q
+        total += 2.0 * p.N * p.H * p.W * p.C
+        if gather:
+            total += M * L.K * (4.0 if L.out_f32 else 2.0)
+            total += (2.0 * M * L.K / (4 ** p.add_shift)) if p.addend else 0.0
+            total += 2.0 * M * L.K if p.mask else 0.0
+        else:
+            total += 2.0 * M * L.K
+    return total
+
+
+def plan_launch_bytes(plan):
+    """Algorithmic HBM bytes of ONE training step of a launch plan, launch by launch: every buffer a launch
+    names (activation, gradient, parameter shadow; exact plan-buffer pointers) counted once at its full size,
+    conv launches by `conv_launch_bytes`.  This is the unfused-per-launch minimum SURVEY 8(d) asks for the HBM-bound
+    EfficientDet configs: a launch that re-reads its inputs moves MORE than this, one that is served by the
+    caches less.  Table-driven launches (weight prep, fusion weights) name only their table: their parameter
+    traffic (a few MB) is left out."""
+    import ctypes
+    sizes = {}
+    for t in plan.bufs:
+        sizes[t.data_ptr()] = t.numel() * t.element_size()
+    total, per_kernel = 0.0, {}
+    for steps in (plan.prep_steps, plan.fwd_steps, plan.bwd_steps):
+        for fn, args, name in steps:
+            b = 0.0
+            if name in CONV_STEPS:
+                b = conv_launch_bytes(args[0]._obj, name)
+            else:
+                seen = set()
+                for a in args:
+                    v = getattr(a, 'value', None)
+                    if isinstance(a, ctypes.c_void_p) and v in sizes and v not in seen:
+                        seen.add(v)
+                        b += sizes[v]
+            total += b
+            per_kernel[name] = per_kernel.get(name, 0.0) + b
+    return total, per_kernel
+
+
 def measured_traffic(args):
     """HBM-side bytes per step of the conv kernels from the COMMITTED PMC passes (tools/collect_traffic.py;
     FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950): a kept profile of the same
@@ -175,9 +223,9 @@ def time_conv_kernels(plan, iters):
     return e0.elapsed_time(e1) / iters, len(steps)
 
 
-def cpu_baseline(depth, size, sd, num_classes):
-    """fp32 oracle (oracle/ref_cpu.py = CPU port of the reference path) forward + loss + backward
-    on a bounded sample of the same workload."""
+def cpu_baseline(depth, size, sd, num_classes, arch='retinanet'):
+    """fp32 oracle (oracle/ref_cpu.py, oracle/ref_effdet.py = CPU ports of the reference path) forward + loss +
+    backward on a bounded sample of the same workload."""
     from oracle import ref_cpu
     nthreads = torch.get_num_threads()
     B = 2
@@ -185,9 +233,15 @@ def cpu_baseline(depth, size, sd, num_classes):
     ann = torch.from_numpy(synth.synth_annotations(B, size, size, 8, 16, num_classes, seed=2))
     p = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype == np.float32 and 'running' not in k)
          for k, v in sd.items()}
+    if arch != 'retinanet':
+        from oracle import ref_effdet
+        coef = int(arch[-1])
 
     def step():
-        cl, rl = ref_cpu.retinanet_loss(p, img, ann, depth)
+        if arch == 'retinanet':
+            cl, rl = ref_cpu.retinanet_loss(p, img, ann, depth)
+        else:
+            cl, rl = ref_effdet.efficientdet_loss(p, img, ann, coef, num_classes)
         (cl.mean() + rl.mean()).backward()
         for t in p.values():
             t.grad = None
@@ -200,13 +254,14 @@ def cpu_baseline(depth, size, sd, num_classes):
         n += 1
     dt = time.perf_counter() - t0
     return {'value': round(B * n / dt, 3), 'unit': 'images/sec', 'cores': nthreads, 'kind': 'port',
-            'sample': '%d steps of batch %d, RetinaNet-R%d %dx%d fp32 fwd+loss+bwd (no optimizer), '
-                      'torch CPU oracle' % (n, B, depth, size, size)}
+            'sample': '%d steps of batch %d, %s %dx%d fp32 fwd+loss+bwd (no optimizer), torch CPU oracle'
+                      % (n, B, 'RetinaNet-R%d' % depth if arch == 'retinanet' else 'EfficientDet-D' + arch[-1], size, size)}
 
 
-def infer_bench(args, model, name, img, dev):
+def infer_bench(args, model, name, img, dev, emit=True):
     """Inference side of SURVEY 8d: (a) batched heads (`return_head=True`), (b) the reference's B=1 decode
     tail (scores > 0.05, class-agnostic NMS 0.5: retinanet.py:297-318) including the host-visible outputs."""
+    was_training = model.training
     model.eval()
     retina = args.arch == 'retinanet'
 
@@ -231,7 +286,12 @@ def infer_bench(args, model, name, img, dev):
             out['heads_batched'] = {'batch': args.batch, 'value': round(args.batch / t_heads, 2),
                                     'ms_per_batch': round(1e3 * t_heads, 3)}
         out['value'] = out.get('heads_batched', out['b1_decode_nms'])['value']
-    print(json.dumps(out))
+    if was_training:
+        model.train()
+        model.freeze_bn()
+    if emit:
+        print(json.dumps(out))
+    return out
 
 
 def spawn_ranks(args):
@@ -357,7 +417,20 @@ def main():
                    'final_loss': [round(float(v), 5) for v in (loss_acc / (args.warmup + args.steps)).tolist()]},
     }
     plan = model._plans[next(iter(model._plans))]
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and args.arch != 'retinanet':
+        # HBM-bound configs (depthwise / SE / BiFPN passes): algorithmic bytes of the step's launches over
+        # the step time, against the HBM peak
+        nbytes, per_kernel = plan_launch_bytes(plan)
+        top = sorted(per_kernel.items(), key=lambda kv: -kv[1])[:4]
+        gbs = nbytes / (median_ms * 1e-3) / 1e9
+        out['roofline'] = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                           'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'traffic_source': None,
+                           'algorithmic_bytes_per_step': round(nbytes),
+                           'kernel': 'whole step (%d launches): every launch\'s operands once; largest by bytes: %s'
+                                     % (len(plan.prep_steps) + len(plan.fwd_steps) + len(plan.bwd_steps),
+                                        ', '.join('%s %.0f MB' % (k.replace('mi355_', ''), v / 1e6) for k, v in top)),
+                           'step_ms_median': round(median_ms, 3)}
+    if rank == 0 and not args.no_roofline and args.arch == 'retinanet':
         fwd_f, train_f = conv_flops(plan)
         conv_ms, nlaunch = time_conv_kernels(plan, 5)
         ach = train_f / (conv_ms * 1e-3) / 1e12
@@ -370,8 +443,11 @@ def main():
                            'kernel': 'conv_gather(+row3, split-K) + conv_wgrad kernels (%d launches/step)' % nlaunch,
                            'algorithmic_gflop_per_image': round(train_f / B / 1e9, 2),
                            'conv_ms_per_step': round(conv_ms, 3)}
-    if rank == 0 and not args.no_cpu_baseline and world == 1 and args.arch == 'retinanet':
-        out['cpu_baseline'] = cpu_baseline(args.depth, S, sd, num_classes)
+    if rank == 0 and world == 1 and not args.no_infer:
+        inf = infer_bench(args, model, name, img, dev, emit=False)         # also inference img/s
+        out['infer'] = {k: inf[k] for k in ('b1_decode_nms', 'heads_batched') if k in inf}
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline(args.depth, S, sd, num_classes, args.arch)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -24,16 +24,23 @@ extern "C" int mi355_version(void) { return 1; }
 // next (hipEventRecord + hipStreamWaitEvent on a small pool of timing-free events; one host call instead
 // of three Python-level ones per weight-gradient launch of the two-stream schedule).
 extern "C" int mi355_stream_fork(void* main_stream, void* side_stream) {
-    constexpr int POOL = 64;
-    static thread_local hipEvent_t ev[POOL];
-    static thread_local int next = -1;
-    if (next < 0) {
-        for (int i = 0; i < POOL; ++i)
-            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return mi355::fail(MI355_ELAUNCH, "stream_fork: event pool");
-        next = 0;
+    // one pool of events per (thread, device): an event belongs to the device that was current when it was made,
+    // and a thread may drive plans on several devices (nn.DataParallel calls forward from one thread per GPU).
+    // Events are made lazily one at a time, so a failure leaves no half-built pool behind.
+    constexpr int POOL = 64, MAXDEV = 16;
+    static thread_local hipEvent_t ev[MAXDEV][POOL];
+    static thread_local int made[MAXDEV] = {0};
+    static thread_local int next[MAXDEV] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return mi355::fail(MI355_ELAUNCH, "stream_fork: device %d", dev);
+    const int slot = next[dev];
+    if (slot >= made[dev]) {
+        if (hipEventCreateWithFlags(&ev[dev][slot], hipEventDisableTiming) != hipSuccess)
+            return mi355::fail(MI355_ELAUNCH, "stream_fork: event pool");
+        made[dev] = slot + 1;
     }
-    hipEvent_t e = ev[next];
-    next = (next + 1) % POOL;
+    hipEvent_t e = ev[dev][slot];
+    next[dev] = (slot + 1) % POOL;
     if (hipEventRecord(e, (hipStream_t)main_stream) != hipSuccess) return mi355::fail(MI355_ELAUNCH, "stream_fork: record");
     if (hipStreamWaitEvent((hipStream_t)side_stream, e, 0) != hipSuccess) return mi355::fail(MI355_ELAUNCH, "stream_fork: wait");
     return MI355_OK;
@@ -810,78 +817,126 @@ __global__ void nms_gather_boxes_kernel(const unsigned long long* __restrict__ k
     sorted_boxes[i] = boxes[src];
 }
 
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ sb, int K, int W,
-                                                      float thr, unsigned long long* __restrict__ mask) {
-    const int jt = blockIdx.x, it = blockIdx.y;
-    if (jt < it) return;
-    __shared__ float4 cols[64];
-    const int lane = threadIdx.x;
-    const int j0 = jt * 64, i = it * 64 + lane;
-    cols[lane] = (j0 + lane < K) ? sb[j0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    if (i >= K) return;
-    const float4 a = sb[i];
+// Upper-triangle suppression bit matrix: mask[i][jt] bit c = (IoU(box i, box jt*64 + c) > thr) for j > i, i and j in
+// descending-score order.  One block = row tile `it` (64 boxes, one per lane) x a quarter of the column tiles
+// jt >= it (the four waves of a block take every fourth of them): ~(W/4) tile pairs per block instead of one
+// 64-thread block per pair (half of which exited at once).  Words with jt < it are never written nor read.
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float4* __restrict__ sb, int K, int W,
+                                                       float thr, unsigned long long* __restrict__ mask) {
+    const int it = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = it * 64 + lane;
+    const float4 a = i < K ? sb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float area_a = (a.z - a.x) * (a.w - a.y);
-    unsigned long long bits = 0;
-    const int nc = min(64, K - j0);
-    for (int c = 0; c < nc; ++c) {
-        const int j = j0 + c;
-        if (j <= i) continue;
-        const float4 b = cols[c];
-        const float area_b = (b.z - b.x) * (b.w - b.y);
-        const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.0f);
-        const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.0f);
-        const float inter = w * h;
-        const float iou = __fdiv_rn(inter, (area_a + area_b) - inter);
-        if (iou > thr) bits |= (1ull << c);
+    for (int jt = it + part * 4 + wv; jt < W; jt += 4 * nparts) {
+        const int j0 = jt * 64;
+        const float4 mine = (j0 + lane < K) ? sb[j0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned long long bits = 0;
+        const int nc = min(64, K - j0);
+        for (int c = 0; c < nc; ++c) {                       // uniform loop: column box by lane broadcast
+            float4 b;
+            b.x = __shfl(mine.x, c, 64); b.y = __shfl(mine.y, c, 64);
+            b.z = __shfl(mine.z, c, 64); b.w = __shfl(mine.w, c, 64);
+            const float area_b = (b.z - b.x) * (b.w - b.y);
+            const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.0f);
+            const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.0f);
+            const float inter = w * h;
+            const float iou = __fdiv_rn(inter, (area_a + area_b) - inter);
+            if (j0 + c > i && iou > thr) bits |= (1ull << c);
+        }
+        if (i < K) mask[(size_t)i * W + jt] = bits;
     }
-    mask[(size_t)i * W + jt] = bits;
 }
 
-__global__ __launch_bounds__(1024) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
-                                                         const int32_t* __restrict__ sorted_idx, int K,
-                                                         int W, int32_t* __restrict__ keep_out,
-                                                         int32_t* __restrict__ d_num_keep) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long removed[];   // [W]
-    __shared__ unsigned long long s_kept;
-    __shared__ int s_nkeep;
+// Greedy sweep in steps of SW_S = 1024 boxes (SW_T = 16 mask words).  The serial part of NMS is cheap when the
+// bits are on chip (~10 cycles per box); what made a tile-by-tile sweep slow is one dependent HBM round trip per
+// 64 boxes.  Per step: `nms_resolve_kernel` (ONE block) stages the 1024 x 1024 diagonal bit block in LDS and one
+// wave walks the boxes in order against the running `removed` words; `nms_propagate_kernel` (many blocks) then
+// ORs the mask rows of the step's kept boxes into the `removed` words of all later boxes at chip bandwidth.
+constexpr int SW_S = 1024, SW_T = 16, SW_LD = 17;          // LDS row stride in words (odd: conflict-free row writes)
+
+__global__ __launch_bounds__(1024) void nms_resolve_kernel(const unsigned long long* __restrict__ mask,
+                                                           const int32_t* __restrict__ sorted_idx, int K, int W, int step,
+                                                           unsigned long long* __restrict__ removed,
+                                                           unsigned long long* __restrict__ kept_bits,
+                                                           int32_t* __restrict__ keep_out, int32_t* __restrict__ d_num_keep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long diag[];      // [SW_S][SW_LD]
+    __shared__ unsigned long long s_kept[SW_T];
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int w = tid; w < W; w += 1024) removed[w] = 0ull;
-    if (tid == 0) s_nkeep = 0;
-    __syncthreads();
-    for (int it = 0; it < W; ++it) {
-        const int r0 = it * 64;
-        const int nr = min(64, K - r0);
-        if (tid < 64) {
-            unsigned long long d = (lane < nr) ? mask[(size_t)(r0 + lane) * W + it] : 0ull;
-            unsigned long long rem = removed[it];
-            unsigned long long kept = 0ull;
-            for (int r = 0; r < nr; ++r) {                       // uniform loop, v_readlane
-                const unsigned long long dr = __shfl(d, r, 64);
-                if (!((rem >> r) & 1ull)) { kept |= (1ull << r); rem |= dr; }
-            }
-            if (lane == 0) s_kept = kept;
-            if ((kept >> lane) & 1ull) {
-                const int pos = s_nkeep + __popcll(kept & ((1ull << lane) - 1ull));
-                keep_out[pos] = sorted_idx[r0 + lane];
-            }
+    const int t0 = step * SW_T, r0 = step * SW_S;
+    const int nr = min(SW_S, K - r0), nt = min(SW_T, W - t0);
+    {                                                          // row tid of the diagonal block (upper triangle only)
+        const int own = tid >> 6;
+        for (int w = 0; w < SW_T; ++w) {
+            unsigned long long v = 0ull;
+            if (tid < nr && w < nt && w >= own) v = mask[(size_t)(r0 + tid) * W + t0 + w];
+            diag[tid * SW_LD + w] = v;
         }
-        __syncthreads();
-        const unsigned long long kept = s_kept;
-        if (tid == 0) s_nkeep += __popcll(kept);
-        for (int w = it + 1 + tid; w < W; w += 1024) {
-            unsigned long long acc = removed[w];
-            unsigned long long k2 = kept;
-            while (k2) {
-                const int r = __ffsll((long long)k2) - 1;
-                k2 &= k2 - 1;
-                acc |= mask[(size_t)(r0 + r) * W + w];
-            }
-            removed[w] = acc;
-        }
-        __syncthreads();
     }
-    if (tid == 0) *d_num_keep = s_nkeep;
+    __syncthreads();
+    if (tid < 64) {
+        const int l16 = lane & 15;
+        unsigned long long rem = (lane < nt) ? removed[t0 + lane] : ~0ull;       // lanes 0..15: this step's words
+        unsigned long long kept = 0ull;
+        for (int wd = 0; wd < nt; ++wd) {
+            unsigned long long cur = __shfl(rem, wd, 64);                          // word of the 64 boxes being walked
+            const int nb = min(64, nr - wd * 64);
+            unsigned long long kw = 0ull;
+            for (int bit = 0; bit < nb; ++bit) {
+                const unsigned long long row = diag[(wd * 64 + bit) * SW_LD + l16];   // (issued ahead of the decision)
+                if (!((cur >> bit) & 1ull)) {                                       // uniform
+                    kw |= 1ull << bit;
+                    rem |= row;
+                    cur |= __shfl(row, wd, 64);
+                }
+            }
+            if (lane == wd) kept = kw;
+        }
+        if (lane < SW_T) s_kept[lane] = lane < nt ? kept : 0ull;
+        if (lane < nt) kept_bits[t0 + lane] = kept;
+    }
+    __syncthreads();
+    // kept boxes -> keep_out, in order
+    const int base = *d_num_keep;
+    int before = 0, total = 0;
+    for (int w = 0; w < SW_T; ++w) {
+        const int c = __popcll(s_kept[w]);
+        if (w < (tid >> 6)) before += c;
+        total += c;
+    }
+    const unsigned long long mine = s_kept[tid >> 6];
+    if (tid < nr && ((mine >> lane) & 1ull))
+        keep_out[base + before + __popcll(mine & ((1ull << lane) - 1ull))] = sorted_idx[r0 + tid];
+    __syncthreads();
+    if (tid == 0) *d_num_keep = base + total;
+}
+
+__global__ __launch_bounds__(256) void nms_propagate_kernel(const unsigned long long* __restrict__ mask, int K, int W,
+                                                            int step, const unsigned long long* __restrict__ kept_bits,
+                                                            unsigned long long* __restrict__ removed) {
+    const int t0 = step * SW_T, r0 = step * SW_S;
+    const int w = t0 + SW_T + blockIdx.x * 256 + threadIdx.x;
+    if (w >= W) return;
+    unsigned long long acc = removed[w];
+    const int nt = min(SW_T, W - t0);
+    for (int kwi = 0; kwi < nt; ++kwi) {
+        unsigned long long k2 = kept_bits[t0 + kwi];                                // uniform
+        const unsigned long long* rowbase = mask + (size_t)(r0 + kwi * 64) * W + w;
+        while (k2) {                                                                // up to 4 independent loads in flight
+            int r[4];
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                r[u] = 0;
+                if (k2) { r[u] = __ffsll((long long)k2) - 1; k2 &= k2 - 1; n = u + 1; }
+            }
+            unsigned long long v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = u < n ? rowbase[(size_t)r[u] * W] : 0ull;
+            acc |= (v[0] | v[1]) | (v[2] | v[3]);
+        }
+    }
+    removed[w] = acc;
 }
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -890,7 +945,7 @@ extern "C" int mi355_nms_workspace_bytes(int K, int64_t* bytes) {
     MI355_REQUIRE(K >= 0 && bytes, "nms_workspace_bytes: bad args");
     int64_t K2 = next_pow2(K < SORT_CHUNK ? SORT_CHUNK : K);
     int64_t W = cdiv(K, 64);
-    *bytes = K2 * 8 + (int64_t)K * 16 + (int64_t)K * 4 + 64 + (int64_t)K * W * 8 + 256;
+    *bytes = K2 * 8 + (int64_t)K * 16 + (int64_t)K * 4 + 64 + (int64_t)K * W * 8 + 256 + 2 * (W * 8 + 64);
     return MI355_OK;
 }
 
@@ -911,12 +966,13 @@ extern "C" int mi355_nms(const float* boxes, const float* scores, int K, float i
                                             (long long)workspace_bytes, (long long)need);
     const int K2 = next_pow2(K < SORT_CHUNK ? SORT_CHUNK : K);
     const int W = (int)cdiv(K, 64);
-    MI355_REQUIRE((int64_t)W * 8 <= 150 * 1024, "nms: K too large for the sweep bitmap in LDS");
     char* p = (char*)workspace;
     unsigned long long* keys = (unsigned long long*)p;  p += (int64_t)K2 * 8;
     float4* sboxes = (float4*)p;                        p += (int64_t)K * 16;
     int32_t* sidx = (int32_t*)p;                        p += (((int64_t)K * 4 + 63) / 64) * 64;
-    unsigned long long* mask = (unsigned long long*)p;
+    unsigned long long* mask = (unsigned long long*)p;              p += (int64_t)K * W * 8;
+    unsigned long long* removed = (unsigned long long*)p;           p += (((int64_t)W * 8 + 63) / 64) * 64;
+    unsigned long long* kept_bits = (unsigned long long*)p;
 
     hipLaunchKernelGGL(nms_make_keys_kernel, dim3(K2 / 256), dim3(256), 0, st, scores, K, K2, keys);
     hipLaunchKernelGGL(bitonic_chunk_sort_kernel, dim3(K2 / SORT_CHUNK), dim3(256), 0, st, keys);
@@ -927,8 +983,23 @@ extern "C" int mi355_nms(const float* boxes, const float* scores, int K, float i
     }
     hipLaunchKernelGGL(nms_gather_boxes_kernel, dim3((unsigned)cdiv(K, 256)), dim3(256), 0, st, keys,
                        (const float4*)boxes, K, sboxes, sidx);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(W, W), dim3(64), 0, st, sboxes, K, W, iou_thr, mask);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(1024), (size_t)W * 8, st, mask, sidx, K, W,
-                       keep_out, d_num_keep);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(W, 4), dim3(256), 0, st, sboxes, K, W, iou_thr, mask);
+    if (hipMemsetAsync(removed, 0, (size_t)W * 8, st) != hipSuccess || hipMemsetAsync(d_num_keep, 0, 4, st) != hipSuccess)
+        return fail(MI355_ELAUNCH, "nms: memset failed");
+    static bool attr_set = false;
+    constexpr size_t DIAG_BYTES = (size_t)SW_S * SW_LD * 8;           // 136 KiB of the 160 KiB LDS
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)nms_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_BYTES);
+        attr_set = true;
+    }
+    const int nsteps = (int)cdiv(K, SW_S);
+    for (int step = 0; step < nsteps; ++step) {
+        hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), DIAG_BYTES, st, mask, sidx, K, W, step, removed,
+                           kept_bits, keep_out, d_num_keep);
+        const int rest = W - (step + 1) * SW_T;
+        if (rest > 0)
+            hipLaunchKernelGGL(nms_propagate_kernel, dim3((unsigned)cdiv(rest, 256)), dim3(256), 0, st, mask, K, W, step,
+                               kept_bits, removed);
+    }
     return check_launch("nms");
 }

@@ -107,6 +107,10 @@ class RetinaPlan(object):
         assert self.wgrad_mode in ('slabs', 'atomic')
         self.deterministic = self.wgrad_mode == 'slabs'
         self.use_side = os.environ.get('MI355_SIDE_STREAM', '1') == '1'
+        # MI355_SIDE_STREAMS=2: the weight-gradient launches alternate between TWO side streams (two independent
+        # latency-bound backbone wgrads in flight beside the data-gradient chain)
+        self.n_side = max(1, int(os.environ.get('MI355_SIDE_STREAMS', '1')))
+        self._side2, self._side_rr = None, 0
         self._side, self._side_dirty = None, False
         self._side_ids, self._mark_side = set(), False
         self.last_arena = 0
@@ -180,7 +184,15 @@ class RetinaPlan(object):
                 fn(stream)
                 continue
             if side is not None and (name in self.SIDE_STEPS or id(args) in self._side_ids):
-                ss = c_vp(side.cuda_stream)
+                tgt = side
+                if self.n_side > 1 and name in self.SIDE_STEPS:
+                    self._side_rr += 1
+                    if self._side_rr & 1:
+                        if self._side2 is None:
+                            self._side2 = torch.cuda.Stream(device=self.dev)
+                        tgt = self._side2
+                        self._side2_dirty = True
+                ss = c_vp(tgt.cuda_stream)
                 rc = fork(s, ss) or fn(*args, ss)            # side stream ordered behind main's launches so far
                 self._side_dirty = True
             else:
@@ -193,7 +205,15 @@ class RetinaPlan(object):
             self._side = torch.cuda.Stream(device=self.dev)
         return self._side
 
+    def _fold_side2(self):
+        """Order the primary side stream behind the second one (before anything that needs ALL weight gradients)."""
+        if getattr(self, '_side2_dirty', False):
+            self._side_stream().wait_stream(self._side2)
+            self._side2_dirty = False
+            self._side_dirty = True
+
     def join_side(self):
+        self._fold_side2()
         if getattr(self, '_side_dirty', False):
             torch.cuda.current_stream(self.dev).wait_stream(self._side)
             self._side_dirty = False
@@ -446,7 +466,9 @@ class RetinaPlan(object):
             world = dist.get_world_size(bn.group)
             if world > 1:
                 return True, bn.group, world
-        return False, None, 1
+        # (tests: `bn.force_sync_formula` puts ONE replica on the synchronised normaliser, so that a single process on
+        #  the full batch can be compared with the replicas; world 1 -> no exchange)
+        return bool(getattr(bn, 'force_sync_formula', False)), None, 1
 
     def _bn_allreduce(self, buf, group):
         import torch.distributed as dist
@@ -472,7 +494,7 @@ class RetinaPlan(object):
         lst = self.fwd_steps
         self._step(lst, 'mi355_bn_nhwc_stats', ptr(z), c_vp(0), c_vp(0), f32, c_i64(M), c_int(C), c_int(0), ptr(partials))
         self._step(lst, 'mi355_bn_nhwc_reduce', ptr(partials), c_int(nblk.value), c_int(C), ptr(sums), c_vp(0), c_vp(0))
-        if sync:
+        if sync and world > 1:
             self._pystep(lst, self._bn_allreduce(sums, group), 'py:bn_allreduce')
         track = bn.track_running_stats and bn.running_mean is not None
         plain = type(bn) is torch.nn.BatchNorm2d            # nn.BatchNorm2d.forward counts batches; the sync class does not
@@ -497,7 +519,7 @@ class RetinaPlan(object):
         self._step(lst, 'mi355_bn_nhwc_stats', ptr(g), ptr(z), ptr(state), f32, c_i64(M), c_int(C), c_int(1), ptr(partials))
         self._step(lst, 'mi355_bn_nhwc_reduce', ptr(partials), c_int(partials.shape[0]), c_int(C), ptr(gsums),
                    ptr(self.grad_view(bn.weight, arena)), ptr(self.grad_view(bn.bias, arena)))
-        if sync:
+        if sync and world > 1:
             self._pystep(lst, self._bn_allreduce(gsums, group), 'py:bn_allreduce')
         dz = self.new(tuple(g.shape))
         self._step(lst, 'mi355_bn_nhwc_bwd_apply', ptr(g), ptr(z), ptr(state), ptr(gsums), c_f32(1.0 / (float(M) * world)),
@@ -672,7 +694,11 @@ class RetinaPlan(object):
         """retinanet.py:48-69 reversed -> (gradient of the last stage output, {stage: lateral grad})."""
         g_p3, g_p4, g_p5, g_p6, g_p7 = g_feat
         f = self.fpn
-        self.conv_bwd(f['P7_2'], self.p6relu, g_p7, dx=g_p6, addend=g_p6, mask=self.p6, mask_first=True)
+        # RetinaNet: the heads read the raw P6 (retinanet.py:64-67, P7_1 = nn.ReLU() out of place): only the P7 branch
+        # passes the ReLU mask.  KSevenDet's `F.relu(P6, inplace=True)` (neck/fpn.py:286) rectifies the tensor that is
+        # ALSO handed to the heads: head gradient and P7 gradient are masked together (mask after the addend).
+        self.conv_bwd(f['P7_2'], self.p6relu, g_p7, dx=g_p6, addend=g_p6, mask=self.p6,
+                      mask_first=not getattr(self, 'p6_relu_inplace', False))
         g_c5 = self.conv_bwd(f['P6'], self.c5, g_p6)
         g_p5lat = self.conv_bwd(f['P5_2'], self.p5lat, g_p5)
         g_p4lat = self.conv_bwd(f['P4_2'], self.p4lat, g_p4)
@@ -906,6 +932,7 @@ class RetinaPlan(object):
         steps = self.bwd_steps if arena == 0 else self.bwd_steps_alt
         self._run(steps[self._bwd_pos:seg[0]], st)
         self._bwd_pos = seg[0]
+        self._fold_side2()
         if self._side_active() and self._side_dirty:
             self._run_param_grads(arena, self._side.cuda_stream, (seg[1], seg[2]))
         else:

@@ -639,7 +639,14 @@ class EffDetPlan(RetinaPlan):
             if self.dc_inject is not None:
                 self.dc_u[:self.dc_inject.shape[0]].copy_(self.dc_inject)
             else:
-                self.dc_u.uniform_()                            # device RNG, one uniform per (block, image)
+                # one uniform per (block, image) from a plan-owned device generator seeded per data-parallel rank:
+                # replicas that all start from torch.manual_seed(s) must not drop the same branches of their shards
+                if getattr(self, '_dc_gen', None) is None:
+                    import torch.distributed as dist
+                    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+                    self._dc_gen = torch.Generator(device=self.dev)
+                    self._dc_gen.manual_seed(torch.initial_seed() + 1000003 * rank)
+                self.dc_u.uniform_(generator=self._dc_gen)
         super(EffDetPlan, self).run_heads(img)
 
     def _arena_for_backward(self):

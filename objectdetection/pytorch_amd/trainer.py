@@ -14,6 +14,42 @@ from . import _lib, dp
 from ._lib import c_f32, c_i64, c_int, c_vp, ptr
 
 
+class _FlatAdamWHandle(torch.optim.Optimizer):
+    """The `optimizer` object of the reference loop (train.py:259-268) for the flat-arena trainer: a real
+    torch.optim.Optimizer whose single param_group carries lr / betas / eps / weight_decay, so that
+    `optim.lr_scheduler.ReduceLROnPlateau(optimizer, patience=3, verbose=True)` (train.py:268, stepped at :346)
+    and any other scheduler drive the HIP AdamW launches.  The update itself is `Trainer.step`; `step()` here is a
+    no-op and `zero_grad()` has nothing to do (the plan owns and re-zeroes the gradient arena)."""
+
+    def __init__(self, trainer, params, lr, betas, eps, weight_decay):
+        self._trainer = trainer
+        super(_FlatAdamWHandle, self).__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    def step(self, closure=None):
+        return None
+
+    def zero_grad(self, set_to_none=True):
+        return None
+
+    def state_dict(self):
+        """param_groups as usual; the moments as flat arenas (keys 'exp_avg', 'exp_avg_sq', 'step')."""
+        t = self._trainer
+        d = super(_FlatAdamWHandle, self).state_dict()
+        d['flat_state'] = {'exp_avg': t.m.detach().clone(), 'exp_avg_sq': t.v.detach().clone(),
+                           'opt_state': t.state.detach().clone()}
+        return d
+
+    def load_state_dict(self, d):
+        d = dict(d)
+        flat = d.pop('flat_state', None)
+        super(_FlatAdamWHandle, self).load_state_dict(d)
+        if flat is not None:
+            t = self._trainer
+            t.m.copy_(flat['exp_avg'])
+            t.v.copy_(flat['exp_avg_sq'])
+            t.state.copy_(flat['opt_state'])
+
+
 class Trainer(object):
     def __init__(self, model, lr=1e-4, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8,
                  clip_norm=0.1, group=None, bucket_bytes=0, graph=False, max_annots=128, overlap=True,
@@ -26,9 +62,31 @@ class Trainer(object):
         self.use_graph, self.max_annots = graph, max_annots
         self.overlap, self.segment_bytes = overlap, segment_bytes
         self._graphs = None
-        self.lr, self.wd, self.betas, self.eps, self.clip_norm = lr, weight_decay, betas, eps, clip_norm
+        self.clip_norm = clip_norm
         self.lib = _lib.lib()
         self._flatten()
+        self.optimizer = _FlatAdamWHandle(self, self.params, lr, betas, eps, weight_decay)
+
+    # hyper-parameters live in the optimizer handle's param_group (what LR schedulers edit)
+    @property
+    def lr(self):
+        return self.optimizer.param_groups[0]['lr']
+
+    @lr.setter
+    def lr(self, v):
+        self.optimizer.param_groups[0]['lr'] = v
+
+    @property
+    def wd(self):
+        return self.optimizer.param_groups[0]['weight_decay']
+
+    @property
+    def betas(self):
+        return self.optimizer.param_groups[0]['betas']
+
+    @property
+    def eps(self):
+        return self.optimizer.param_groups[0]['eps']
 
     def _flatten(self):
         """Re-home every parameter into ONE flat fp32 arena (same order as model.parameters(), same
@@ -58,7 +116,9 @@ class Trainer(object):
         return int(self.state[0].item())
 
     def step(self, img, annot):
-        if self.use_graph and not self._overlap():
+        if self.use_graph:
+            # hipGraph replay (forward + loss + backward | clip + AdamW); with more than one rank the gradient arena is
+            # exchanged in ONE all-reduce between the two replays (the overlapped per-range exchange is an eager path)
             return self._step_graph(img, annot)
         if self._overlap():
             # (launched eagerly: the step is GPU-bound, ~260 launches cost ~2 ms of host time per ~14 ms

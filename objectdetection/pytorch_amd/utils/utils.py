@@ -82,5 +82,9 @@ def replace_w_sync_bn(m):
                 new.weight = target_attr.weight
                 new.bias = target_attr.bias
             setattr(m, var_name, new.to(target_attr.running_mean.device))
+    if getattr(m, '_plans', None):                     # launch plans / the cached BN list point at the old modules
+        m._plans.clear()
+    if hasattr(m, '_bn_list'):
+        m._bn_list = None
     for var_name, children in m.named_children():
         replace_w_sync_bn(children)

@@ -1,0 +1,272 @@
+"""GPU: train-mode / synchronised BatchNorm INSIDE the launch plans (csrc/bn_nhwc.hip, include/mi355det_bn.h).
+
+(1) the NHWC passes through the C ABI against a fixture made with the reference's own SynchronizedBatchNorm2d
+    statistics (`_compute_mean_std`, utils/sync_batchnorm/batchnorm.py:128-145) and output formula (:86), incl. a
+    channel whose variance is below eps (clamp active) and the two-replica split of the sums;
+(2) a RetinaNet left in train mode (BN not frozen) against a golden produced by the reference itself;
+(3) two ranks with `replace_w_sync_bn` (utils/utils.py:140-168) on B images each == one process on the 2B batch;
+(4) data parallel with frozen BN: DP(2 x B) == the single-process 2B step (loss and gradient arena)."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _c():
+    from objectdetection.pytorch_amd import _lib
+    return _lib
+
+
+def _bn_passes(x_nhwc, dy_nhwc, weight, bias, eps, momentum, rm, rv, clamp, split=1):
+    """Drive the six passes on [M][C] tensors (fp32 or bf16); `split` emulates that many replicas by reducing the
+    row blocks separately and adding the sums (what the all-reduce does)."""
+    L = _c()
+    from objectdetection.pytorch_amd._lib import c_f32, c_i64, c_int, c_vp, ptr
+    dev = x_nhwc.device
+    C = x_nhwc.shape[-1]
+    f32 = c_int(1 if x_nhwc.dtype == torch.float32 else 0)
+    st = c_vp(torch.cuda.current_stream().cuda_stream)
+    rows = x_nhwc.reshape(-1, C)
+    M = rows.shape[0]
+    parts = [rows[i * M // split:(i + 1) * M // split].contiguous() for i in range(split)]
+
+    def sums_of(tensors, bwd, zs=None, state=None):
+        total = torch.zeros(2 * C, device=dev)
+        local = []
+        for i, t in enumerate(tensors):
+            nblk, rpb = ctypes.c_int(), ctypes.c_int()
+            L.call('mi355_bn_nhwc_partial_blocks', c_i64(t.shape[0]), c_int(C), ctypes.byref(nblk), ctypes.byref(rpb))
+            partials = torch.empty((nblk.value, 2 * C), device=dev)
+            L.call('mi355_bn_nhwc_stats', ptr(t), ptr(zs[i]) if bwd else c_vp(0), ptr(state), f32, c_i64(t.shape[0]),
+                   c_int(C), c_int(1 if bwd else 0), ptr(partials), st)
+            s = torch.empty(2 * C, device=dev)
+            L.call('mi355_bn_nhwc_reduce', ptr(partials), c_int(nblk.value), c_int(C), ptr(s), c_vp(0), c_vp(0), st)
+            local.append(s)
+            total += s
+        return total, local
+    sums, _ = sums_of(parts, False)
+    state = torch.empty(5 * C, device=dev)
+    L.call('mi355_bn_nhwc_finalize', ptr(sums), c_f32(float(M)), c_int(C), c_f32(eps), c_f32(momentum), c_int(clamp),
+           ptr(weight), ptr(bias), ptr(rm), ptr(rv), c_vp(0), ptr(state), st)
+    y = torch.empty_like(rows)
+    L.call('mi355_bn_nhwc_apply', ptr(rows), ptr(state), c_vp(0), c_int(0), f32, c_i64(M), c_int(C), ptr(y), st)
+    g = dy_nhwc.reshape(-1, C)
+    gparts = [g[i * M // split:(i + 1) * M // split].contiguous() for i in range(split)]
+    gsums, local = sums_of(gparts, True, parts, state)
+    dx = torch.empty_like(rows)
+    L.call('mi355_bn_nhwc_bwd_apply', ptr(g.contiguous()), ptr(rows), ptr(state), ptr(gsums), c_f32(1.0 / M), f32,
+           c_i64(M), c_int(C), ptr(dx), st)
+    return y, dx, gsums[C:], gsums[:C], state
+
+
+@pytest.mark.parametrize('split', [1, 2])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_bn_passes_vs_reference_syncbn_fixture(golden_dir, split, dtype):
+    g = np.load(os.path.join(golden_dir, 'syncbn.npz'))
+    dev = torch.device('cuda', 0)
+    dt = torch.float32 if dtype == 'fp32' else torch.bfloat16
+    x = torch.from_numpy(g['x'])
+    N, C, H, W = x.shape
+    if dtype == 'bf16':                                   # the fixture is fp32: compare on bf16-representable inputs
+        pytest.skip('bf16 storage of this pass is exercised end to end (test_trainbn_plan...)') if split == 2 else None
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(dt)
+    dyh = torch.from_numpy(g['dy']).permute(0, 2, 3, 1).contiguous().to(dev).to(dt)
+    rm, rv = torch.from_numpy(g['running_mean0']).to(dev), torch.from_numpy(g['running_var0']).to(dev)
+    y, dx, dw, db, state = _bn_passes(xh, dyh, torch.from_numpy(g['weight']).to(dev), torch.from_numpy(g['bias']).to(dev),
+                                      float(g['eps']), float(g['momentum']), rm, rv, 1, split)
+    tol = 2e-5 if dtype == 'fp32' else 2e-2
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    y = y.float().view(N, H, W, C).permute(0, 3, 1, 2).cpu().numpy()
+    dx = dx.float().view(N, H, W, C).permute(0, 3, 1, 2).cpu().numpy()
+    assert rel(y, g['y']) < tol
+    assert rel(dx, g['dx']) < (2e-4 if dtype == 'fp32' else 5e-2)        # clamp channel: invstd = 100, fp32 cancellation
+    assert rel(dw.cpu().numpy(), g['dweight']) < (1e-4 if dtype == 'fp32' else 5e-2)
+    assert rel(db.cpu().numpy(), g['dbias']) < (1e-5 if dtype == 'fp32' else 2e-2)
+    if dtype == 'fp32':
+        np.testing.assert_allclose(state[:C].cpu().numpy(), g['mean'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(state[C:2 * C].cpu().numpy(), g['inv_std'], rtol=1e-4)
+        assert state[4 * C].item() == 0.0 and state[4 * C + 1].item() == 1.0     # channel 0: clamp active
+        np.testing.assert_allclose(rm.cpu().numpy(), g['running_mean1'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rv.cpu().numpy(), g['running_var1'], rtol=1e-5, atol=1e-6)
+
+
+def _trainbn_model(dev, g, precision):
+    from objectdetection.pytorch_amd.architectures import retinanet
+    depth, nc = int(g['depth']), int(g['num_classes'])
+    model = retinanet.retinanet(depth, num_classes=nc)
+    model.precision = precision
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=float(g['gain']))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    model.train()                                             # BN stays in train mode (no freeze_bn)
+    return model
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_trainbn_plan_vs_reference_golden(golden_dir, precision):
+    g = np.load(os.path.join(golden_dir, 'e2e_r18_trainbn_128.npz'))
+    dev = torch.device('cuda', 0)
+    (H, W), B, nc = g['hw'], int(g['batch']), int(g['num_classes'])
+    model = _trainbn_model(dev, g, precision)
+    img = torch.from_numpy(synth.synth_images(B, int(H), int(W), seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(B, int(H), int(W), 8, 16, nc, seed=2)).to(dev)
+    cl, rl = model(img, ann)
+    ltol = 1e-4 if precision == 'fp32' else 3e-2
+    np.testing.assert_allclose(cl.item(), g['cls_loss'].item(), rtol=ltol)
+    np.testing.assert_allclose(rl.item(), g['reg_loss'].item(), rtol=ltol)
+    sd = model.state_dict()
+    for key in g.files:
+        if key.startswith('running/'):
+            name = key[8:]
+            got = sd[name].cpu().numpy()
+            if name.endswith('num_batches_tracked'):
+                assert int(got) == int(g[key]) == 1
+            else:
+                np.testing.assert_allclose(got, g[key], rtol=1e-4 if precision == 'fp32' else 2e-2,
+                                           atol=1e-6 if precision == 'fp32' else 2e-3)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = dict((k, p.grad) for k, p in model.named_parameters())
+    gn = np.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values()))
+    np.testing.assert_allclose(gn, float(g['grad_global_norm']), rtol=1e-3 if precision == 'fp32' else 8e-2)
+    for key in g.files:
+        if key.startswith('grad/') and key.endswith('/val'):
+            name = key[5:-4]
+            sel = torch.from_numpy(g['grad/%s/idx' % name]).to(dev)
+            got = grads[name].reshape(-1)[sel].cpu().numpy().astype(np.float64)
+            ref, ref64 = g[key].astype(np.float64), g['grad64/%s/val' % name].astype(np.float64)
+            if np.linalg.norm(ref64) < 1e-9 * gn:           # conv bias-free weights in front of a BN: ~0 by symmetry
+                assert np.linalg.norm(got) < 1e-4 * gn, name
+                continue
+            noise = float(np.linalg.norm(ref - ref64) / np.linalg.norm(ref64))
+            e32 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            print('  %-40s reference fp32-vs-fp64 %.2e | ours vs golden %.2e' % (name, noise, e32))
+            if precision == 'fp32':
+                assert e32 <= max(1e-3, 3.0 * noise), (name, e32, noise)
+            else:
+                cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+                # (conv1.weight and the stem BN behind it: the ill-conditioned stem sums, see test_gpu_retinanet.TWIN_REL_L2_STEM)
+                print('      cosine %.4f' % cos)
+                assert cos > (0.8 if name.startswith(('conv1.', 'bn1.')) else 0.9), (name, cos)
+    # eval after training steps uses the running statistics (folded again): a different plan, finite output
+    model.eval()
+    s, c, b = model(img[:1], return_loss=False)
+    assert torch.isfinite(s).all()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _small_model(dev, sync, precision='fp32'):
+    from objectdetection.pytorch_amd.architectures import retinanet
+    from objectdetection.pytorch_amd.utils.utils import replace_w_sync_bn
+    model = retinanet.retinanet(18, num_classes=8)
+    model.precision = precision
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=0.87)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    if sync:
+        replace_w_sync_bn(model)                              # utils/utils.py:140-168
+        # (the reference walks `dir(m)`, which hides the numeric attribute names of nn.Sequential: the BN of every
+        #  `downsample = Sequential(conv, bn)` stays a plain nn.BatchNorm2d with per-replica statistics, here as
+        #  there.  This test wants EVERY layer synchronised, so those are converted by hand.)
+        from objectdetection.pytorch_amd.utils.sync_batchnorm import SynchronizedBatchNorm2d
+        assert type(model.layer2[0].downsample[1]) is torch.nn.BatchNorm2d
+        assert type(model.bn1) is SynchronizedBatchNorm2d
+        for mod in list(model.modules()):
+            if isinstance(mod, torch.nn.Sequential):
+                for i, ch in enumerate(mod):
+                    if type(ch) is torch.nn.BatchNorm2d:
+                        new = SynchronizedBatchNorm2d(ch.num_features, ch.eps, ch.momentum, ch.affine)
+                        new.load_state_dict(ch.state_dict())
+                        new.weight, new.bias = ch.weight, ch.bias
+                        mod[i] = new
+    model = model.to(dev)
+    model.train()
+    if not sync:
+        model.freeze_bn()
+    return model
+
+
+def _batch(dev, lo, hi):
+    img = torch.from_numpy(synth.synth_images(4, 128, 128, seed=1))[lo:hi].contiguous().to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(4, 128, 128, 6, 8, 8, seed=2))[lo:hi].contiguous().to(dev)
+    return img, ann
+
+
+def _step_arrays(model, img, ann, group_size):
+    import torch.distributed as dist
+    cl, rl = model(img, ann)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    plan = model._plans[next(reversed(model._plans))]
+    arena = plan.grad_arenas[plan.last_arena].clone()
+    losses = torch.cat([cl.detach(), rl.detach()])
+    if group_size > 1:                                        # the DP exchange: average gradients and losses
+        dist.all_reduce(arena)
+        dist.all_reduce(losses)
+        arena /= group_size
+        losses /= group_size
+    rs = {k: v.cpu().numpy() for k, v in model.state_dict().items() if 'running' in k and k.startswith(('bn1', 'layer4.1.bn2'))}
+    return losses.cpu().numpy(), arena.cpu().numpy(), rs
+
+
+def _bn_worker(rank, world, port, out, sync):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda', 0)
+        model = _small_model(dev, sync)
+        img, ann = _batch(dev, 2 * rank, 2 * rank + 2)
+        out[rank] = _step_arrays(model, img, ann, world)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('sync', [True, False])
+def test_two_ranks_equal_single_process_on_the_full_batch(sync):
+    """sync=True: plan + SynchronizedBatchNorm2d on 2 x B images == the single process on 2B images (its BN forced
+    onto the synchronised formula, batchnorm.py:145: a clamp, where one replica would take F.batch_norm's + eps).
+    sync=False: frozen BN, DP(2 x B) with averaged gradients == the single-process 2B step."""
+    import torch.multiprocessing as mp
+    dev = torch.device('cuda', 0)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bn_worker, args=(2, _free_port(), out, sync), nprocs=2, join=True)
+    model = _small_model(dev, sync)
+    if sync:
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.force_sync_formula = True
+    img, ann = _batch(dev, 0, 4)
+    losses, arena, rs = _step_arrays(model, img, ann, 1)
+    l0, a0, r0 = out[0]
+    l1, a1, r1 = out[1]
+    assert np.array_equal(a0, a1) and np.array_equal(l0, l1)          # replicas agree bit for bit after the exchange
+    np.testing.assert_allclose(l0, losses, rtol=2e-5)
+    err = np.linalg.norm(a0.astype(np.float64) - arena) / np.linalg.norm(arena)
+    # fp32 mode: summation order plus the ReLU-mask flips it causes.  Frozen BN: 2e-4.  Batch statistics make every
+    # activation depend on every pixel of its channel, so the flips spread: the reference's own fp32 run of the
+    # train-BN model is 1e-3 .. 2e-3 from its fp64 value (tests/golden/e2e_r18_trainbn_128.npz grad64/*)
+    assert err < (5e-3 if sync else 2e-4), err
+    for k in rs:
+        np.testing.assert_allclose(r0[k], rs[k], rtol=1e-5, atol=1e-6)
+        if sync:
+            assert np.array_equal(r0[k], r1[k])                       # synchronised: every replica tracks the same statistics

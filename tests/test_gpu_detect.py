@@ -137,7 +137,7 @@ def _rand_boxes(rng, n, span=200.0, size=60.0):
     return np.concatenate([xy, xy + wh], 1).astype(np.float32)
 
 
-@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 1000, 2048, 2049, 5000, 20000])
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 1000, 1023, 1024, 1025, 2048, 2049, 5000, 20000, 46706])
 def test_nms_vs_oracle_bit_exact(dev, n):
     from objectdetection.pytorch_amd import ops_detect
     rng = np.random.default_rng(n)

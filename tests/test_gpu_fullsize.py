@@ -111,3 +111,92 @@ def test_training_step_properties_at_configs1_size(monkeypatch):
 
 def A_positive(losses):
     return bool((losses > 0).all()) and bool(torch.isfinite(losses).all())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The other BASELINE.json configs at their full sizes: configs[2] RetinaNet-R50 640 x 640 bs16 (its SyncBN
+# part: test_gpu_bn_plan.py), configs[3] EfficientDet-D0 512 x 512 bs16, configs[4] EfficientDet-D2 768 x 768 bs8.
+@pytest.mark.parametrize('arch,size,batch', [('retinanet', 640, 16), ('efficientdet-d0', 512, 16),
+                                             ('efficientdet-d2', 768, 8)])
+def test_training_step_properties_at_other_config_sizes(monkeypatch, arch, size, batch):
+    """Run-to-run reproducibility, duplicate-batch invariance of the per-image-normalised losses (losses.py:118,
+    :161, :168) and of the mean gradient, finite positive losses, at the full size of the config."""
+    import bench
+    monkeypatch.setenv('MI355_DETERMINISTIC', '1')
+    retina = arch == 'retinanet'
+    model = bench.build_model(50, 80, DEV, arch)[0]
+    if not retina:
+        synth.disable_drop_connect(model)                  # (its draws differ per image: not duplicate-invariant)
+    half = batch // 2
+    imgh = torch.from_numpy(synth.synth_images(half, size, size, seed=1)).to(DEV)
+    annh = torch.from_numpy(synth.synth_annotations(half, size, size, 8, 16, 80, seed=2)).to(DEV)
+    img, ann = torch.cat([imgh, imgh]), torch.cat([annh, annh])
+
+    def run(i, a):
+        model.zero_grad()
+        cl, rl = model(i, a)
+        (cl + rl).sum().backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+        return torch.stack([cl.detach().reshape(()), rl.detach().reshape(())]), grads.clone()
+
+    l1, g1 = run(img, ann)
+    l2, g2 = run(img, ann)
+    assert A_positive(l1)
+    if retina:
+        assert torch.equal(l1, l2) and torch.equal(g1, g2)                # slab split-K: bit-reproducible
+    else:                                                                  # (shared-head dW / SE sums still use fp32 atomics)
+        assert torch.equal(l1, l2)
+        assert float((g1 - g2).norm() / g1.norm()) <= 1e-5
+    lh, gh = run(imgh, annh)
+    # (the half-batch launches take other tile shapes / slab counts: bf16 activations differ in the last bit, and
+    #  ~100 bf16 layers of EfficientDet amplify that more than RetinaNet's ~60)
+    np.testing.assert_allclose(l1.cpu().numpy(), lh.cpu().numpy(), rtol=5e-4 if retina else 2e-2)
+    cos = float((g1.double() * gh.double()).sum() / (g1.double().norm() * gh.double().norm()))
+    assert cos >= (1 - 2e-4 if retina else 0.995), cos
+    assert abs(float(g1.norm()) / float(gh.norm()) - 1.0) <= (5e-3 if retina else 5e-2)
+
+
+def test_depthwise_and_bifpn_node_at_d0_full_size():
+    """fp64 spot checks at EfficientDet-D0 512 x 512 bs16 sizes: the first MBConv depthwise conv (16 x 256 x 256 x 32,
+    k3 s1, swish on load, efficientnet.py:87-95) and a BiFPN P3 node (16 x 64 x 64 x 64 + upsampled 32 x 32,
+    efficientdet.py:213-265)."""
+    from objectdetection.pytorch_amd import ops_effdet as E
+    from objectdetection.pytorch_amd._lib import call, ptr, c_int, stream_of
+    N, H, W, C, k = 16, 256, 256, 32, 3
+    z = _rand_bf16((N, H, W, C), 1)
+    g = torch.Generator().manual_seed(2)
+    w = (torch.randn((C, 1, k, k), generator=g) * 0.3).to(DEV)
+    scale = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    w_t = torch.empty((k * k, C), device=DEV)
+    E.dw_prep_weight(w.contiguous(), scale, w_t)
+    y = E.dwconv_fwd(z, True, w_t, shift, k, 1)
+    assert torch.equal(E.dwconv_fwd(z, True, w_t, shift, k, 1), y)        # reproducible
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(3)).to(DEV)
+    assert torch.equal(E.dwconv_fwd(z[perm].contiguous(), True, w_t, shift, k, 1), y[perm])
+    zc, wc = z.float().cpu().double(), (w * scale[:, None, None, None]).cpu().double()
+    sw = zc * torch.sigmoid(zc)
+    for n, p, q, c in ((0, 0, 0, 0), (15, 255, 255, 31), (7, 0, 100, 5), (3, 128, 255, 17), (9, 77, 33, 20)):
+        acc = float(shift[c])
+        for r in range(k):
+            for s in range(k):
+                h, ww = p - 1 + r, q - 1 + s
+                if 0 <= h < H and 0 <= ww < W:
+                    acc += float(sw[n, h, ww, c] * wc[c, 0, r, s])
+        assert abs(float(y[n, p, q, c]) - acc) <= 1e-2 * max(1.0, abs(acc)), (n, p, q, c, float(y[n, p, q, c]), acc)
+    # BiFPN node: z = w0 * a + w1 * up2(b) + w2 * c (pre-activation, swish is applied by the consumer)
+    N, H, W, C = 16, 64, 64, 64
+    a, b, c3 = _rand_bf16((N, H, W, C), 4), _rand_bf16((N, H // 2, W // 2, C), 5), _rand_bf16((N, H, W, C), 6)
+    wd = torch.tensor([0.45, 0.2, 0.35], device=DEV)
+    out = torch.empty_like(a)
+    call('mi355_bifpn_node_fwd', ptr(a), ptr(b), c_int(1), ptr(c3), ptr(wd), ptr(out), c_int(N), c_int(H), c_int(W),
+         c_int(C), stream_of(a))
+    torch.cuda.synchronize()
+    idx = torch.randint(0, N * H * W * C, (4096,), generator=torch.Generator().manual_seed(7))
+    n_, rem = idx // (H * W * C), idx % (H * W * C)
+    p_, rem = rem // (W * C), rem % (W * C)
+    q_, c_ = rem // C, rem % C
+    ac, bc, cc = a.float().cpu().double(), b.float().cpu().double(), c3.float().cpu().double()
+    ref = 0.45 * ac[n_, p_, q_, c_] + float(np.float32(0.2)) * bc[n_, p_ // 2, q_ // 2, c_] + float(np.float32(0.35)) * cc[n_, p_, q_, c_]
+    got = out.float().cpu().double()[n_, p_, q_, c_]
+    assert float((got - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())

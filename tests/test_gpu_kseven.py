@@ -1,0 +1,107 @@
+"""GPU: the KSevenDet family (ksevendet/architecture/ksevendet.py:20-301) on its launch plan against
+goldens computed with the reference's own neck (neck/fpn.py PANetFPN), heads (head/simple_head.py: shared convs +
+per-level BN) and anchors files, wired as ksevendet.py:197-231 (tools/make_golden.py:gen_e2e_kseven explains why the
+package itself cannot be imported).  fp32 mode at the north-star bounds, bf16 mode at bf16 bounds."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build(g, dev, precision):
+    from objectdetection.pytorch_amd.ksevendet.architecture import ksevendet
+    cfg = yaml.safe_load(open(os.path.join(ROOT, 'objectdetection', 'pytorch_amd', 'config', 'model', 'ksevendet_resnet.yaml')))
+    assert cfg.pop('architecture') == 'ksevendet'
+    cfg['neck'] = str(g['neck'])
+    model = ksevendet.KSevenDet(cfg, num_classes=int(g['num_classes']), pretrained=False)
+    model.precision = precision
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert list(shapes.keys()) == list(g['state_keys'])
+    assert [','.join(map(str, shapes[k])) for k in shapes] == list(g['state_shapes'])
+    sd = synth.synth_state_dict(shapes, seed=0, gain=float(g['gain']))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    model.train()
+    model.freeze_bn()
+    if bool(g['train_bn_heads']):
+        for m in list(model.regressor.bn_modules.modules()) + list(model.classifier.bn_modules.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.train()
+    return model
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('tag', ['kseven_r18_fpn_128x160', 'kseven_r18_panet_128', 'kseven_r18_headbn_128'])
+def test_kseven_vs_reference_golden(golden_dir, tag, precision):
+    g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
+    dev = torch.device('cuda', 0)
+    model = build(g, dev, precision)
+    (H, W), B, nc = g['hw'], int(g['batch']), int(g['num_classes'])
+    img = torch.from_numpy(synth.synth_images(B, int(H), int(W), seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(B, int(H), int(W), 8, 16, nc, seed=2)).to(dev)
+    f32 = precision == 'fp32'
+    np.testing.assert_allclose(model.anchors(img).cpu().numpy(), g['anchors'], rtol=1e-6, atol=1e-4)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    cls, reg = model(img, return_head=True)
+    model.load_state_dict(sd0)                                 # (train-mode head BN moved its running statistics)
+    idx = g['head_idx']
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    assert rel(reg.cpu().numpy()[:, idx], g['reg_rows']) < (1e-4 if f32 else 4e-2)
+    assert rel(cls.cpu().numpy()[:, idx], g['cls_rows']) < (1e-4 if f32 else 4e-2)
+    cl, rl = model(img, ann, return_loss=True)                 # (KSevenDet.forward defaults to return_loss=False, :197)
+    np.testing.assert_allclose(cl.item(), g['cls_loss'].item(), rtol=1e-4 if f32 else 4e-2)
+    np.testing.assert_allclose(rl.item(), g['reg_loss'].item(), rtol=1e-4 if f32 else 4e-2)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = dict((k, p.grad) for k, p in model.named_parameters())
+    assert all(v is not None for v in grads.values())
+    gn = np.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values()))
+    np.testing.assert_allclose(gn, float(g['grad_global_norm']), rtol=1e-3 if f32 else 8e-2)
+    worst = ('', 0.0)
+    for key in g.files:
+        if key.startswith('grad/') and key.endswith('/val'):
+            name = key[5:-4]
+            sel = torch.from_numpy(g['grad/%s/idx' % name]).to(dev)
+            got = grads[name].reshape(-1)[sel].cpu().numpy().astype(np.float64)
+            ref, ref64 = g[key].astype(np.float64), g['grad64/%s/val' % name].astype(np.float64)
+            if np.linalg.norm(ref64) < 1e-7 * gn:              # conv bias in front of a train-mode BN: zero by symmetry
+                assert np.linalg.norm(got) < 1e-4 * gn, (name, np.linalg.norm(got))
+                continue
+            noise = float(np.linalg.norm(ref - ref64) / np.linalg.norm(ref64))
+            e32 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            if e32 > worst[1]:
+                worst = (name, e32)
+            if f32:
+                assert e32 <= max(1e-3, 3.0 * noise), (name, e32, noise)
+            else:
+                cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+                assert cos > (0.8 if name == 'backbone.conv1.weight' else 0.93), (name, cos)
+    print('%s %s: cls %.6g (ref %.6g) worst sampled-grad relL2 %s %.3g' % (tag, precision, cl.item(), g['cls_loss'].item(), worst[0], worst[1]))
+    # decode tail (ksevendet.py:253-286) runs through the shared device path
+    model.eval()
+    s, c, b = model(img[:1])
+    assert c.dtype == torch.int64 and b.shape == (s.numel(), 4) and bool((s[:-1] >= s[1:]).all())
+
+
+def test_kseven_trainer_step(golden_dir):
+    from objectdetection.pytorch_amd.trainer import Trainer
+    g = np.load(os.path.join(golden_dir, 'e2e_kseven_r18_fpn_128x160.npz'))
+    dev = torch.device('cuda', 0)
+    model = build(g, dev, 'bf16')
+    img = torch.from_numpy(synth.synth_images(2, 128, 160, seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(2, 128, 160, 8, 16, int(g['num_classes']), seed=2)).to(dev)
+    tr = Trainer(model)
+    l0 = tr.step(img, ann).clone()
+    for _ in range(3):
+        l1 = tr.step(img, ann)
+    assert torch.isfinite(l1).all() and tr.step_count == 4
+    np.testing.assert_allclose(l0.cpu().numpy(), [g['cls_loss'].item(), g['reg_loss'].item()], rtol=4e-2)

@@ -375,6 +375,186 @@ def gen_e2e(depth, H, W, B, num_classes, tag, gain):
           'gnorm', d['grad_global_norm'])
 
 
+def gen_e2e_trainbn(depth, H, W, B, num_classes, tag, gain):
+    """RetinaNet with BatchNorm left in TRAIN mode (no freeze_bn): batch statistics per layer, running-statistics
+    update, gradients through the normalisation (what `replace_w_sync_bn` + train() gives on one replica,
+    utils/sync_batchnorm/batchnorm.py:65-69 -> F.batch_norm(training=True))."""
+    torch.manual_seed(0)
+    model = ref_retinanet.retinanet(depth, num_classes=num_classes)
+    shapes = load_synth(model, depth, num_classes, gain)
+    model.train()                                                 # BN in train mode: NOT frozen
+    img = synth.synth_images(B, H, W, seed=1)
+    ann = synth.synth_annotations(B, H, W, num_real=8, pad_to=16, num_classes=num_classes, seed=2)
+    img_t, ann_t = torch.from_numpy(img), torch.from_numpy(ann)
+    cl, rl = model(img_t, ann_t)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters()}
+    d = dict(cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(), depth=np.array(depth), hw=np.array([H, W]),
+             batch=np.array(B), num_classes=np.array(num_classes), gain=np.array(gain))
+    keys = [k for k in GRAD_KEYS if k in grads] + ['layer1.0.bn1.weight', 'layer4.1.bn2.bias', 'layer3.0.downsample.1.weight']
+    for k in keys:
+        flat = grads[k].reshape(-1)
+        sel = np.linspace(0, flat.size - 1, min(flat.size, 512)).astype(np.int64)
+        d['grad/' + k + '/idx'] = sel
+        d['grad/' + k + '/val'] = flat[sel]
+    d['grad_global_norm'] = np.array(np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in grads.values())))
+    sd = model.state_dict()
+    for k in ('bn1', 'layer1.0.bn2', 'layer2.0.downsample.1', 'layer4.1.bn2'):     # after ONE forward
+        d['running/' + k + '.running_mean'] = sd[k + '.running_mean'].numpy().copy()
+        d['running/' + k + '.running_var'] = sd[k + '.running_var'].numpy().copy()
+        d['running/' + k + '.num_batches_tracked'] = sd[k + '.num_batches_tracked'].numpy().copy()
+    # fp64 yardstick: reload the same state (the fp32 forward above moved the running statistics)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(shapes, seed=0, gain=gain).items()})
+    _add_fp64_run(d, model, img_t, ann_t, lambda m, i, a: m(i, a), keys)
+    np.savez_compressed(os.path.join(OUT, 'e2e_%s.npz' % tag), **d)
+    print('e2e', tag, 'cls', cl.item(), 'reg', rl.item(), 'gnorm', d['grad_global_norm'])
+
+
+def gen_syncbn():
+    """Statistics and normalisation of the reference's SynchronizedBatchNorm2d in its PARALLEL branch, driven on
+    CPU: `_compute_mean_std` (utils/sync_batchnorm/batchnorm.py:128-145) is the reference's own method, called
+    on an instance with the batch sums of :76-78; the output formula is :86 evaluated with autograd so that the
+    backward through mean / inv_std (incl. the clamp of :145) is the reference's.  Channel 0 has a variance below
+    eps (clamp active)."""
+    from utils.sync_batchnorm.batchnorm import SynchronizedBatchNorm2d as RefSBN
+    g = torch.Generator().manual_seed(7)
+    N, C, H, W = 6, 16, 5, 7
+    x = torch.randn(N, C, H, W, generator=g)
+    x[:, 0] *= 1e-3
+    x[:, 3] += 2.0
+    dy = torch.randn(N, C, H, W, generator=g)
+    bn = RefSBN(C, eps=1e-4, momentum=0.1)
+    bn.weight.data = torch.rand(C, generator=g) + 0.5
+    bn.bias.data = torch.randn(C, generator=g)
+    bn.running_mean = torch.randn(C, generator=g) * 0.1
+    bn.running_var = torch.rand(C, generator=g) + 0.5
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    xr = x.clone().requires_grad_(True)
+    inp = xr.view(N, C, -1)
+    sum_size = N * H * W
+    input_sum = inp.sum(dim=0, keepdim=True).sum(dim=-1, keepdim=True).view(-1)          # _sum_ft, :34-36
+    input_ssum = (inp ** 2).sum(dim=0, keepdim=True).sum(dim=-1, keepdim=True).view(-1)
+    mean, inv_std = bn._compute_mean_std(input_sum, input_ssum, sum_size)
+    out = (inp - mean.unsqueeze(0).unsqueeze(-1)) * (inv_std * bn.weight).unsqueeze(0).unsqueeze(-1) \
+        + bn.bias.unsqueeze(0).unsqueeze(-1)                                             # :86
+    y = out.view(N, C, H, W)
+    (y * dy).sum().backward()
+    d = dict(x=x.numpy(), dy=dy.numpy(), y=y.detach().numpy(), dx=xr.grad.numpy(), dweight=bn.weight.grad.numpy(),
+             dbias=bn.bias.grad.numpy(), weight=bn.weight.detach().numpy(), bias=bn.bias.detach().numpy(),
+             eps=np.array(bn.eps), momentum=np.array(bn.momentum), running_mean0=rm0.numpy(), running_var0=rv0.numpy(),
+             running_mean1=bn.running_mean.numpy(), running_var1=bn.running_var.numpy(),
+             mean=mean.detach().numpy(), inv_std=inv_std.detach().numpy())
+    np.savez_compressed(os.path.join(OUT, 'syncbn.npz'), **d)
+    print('syncbn: clamped channels', int((inv_std.detach() >= bn.eps ** -0.5 * 0.999).sum()))
+
+
+def _load_by_path(name, path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_e2e_kseven(neck, H, W, B, num_classes, tag, gain, train_bn_heads=False):
+    """KSevenDet.  The reference's `ksevendet` PACKAGE cannot be imported, here or anywhere:
+    ksevendet/architecture/backbone/registry.py:32 is a SyntaxError (`model_name inSelectAdaptivePool2d
+    mod.default_cfgs`) and backbone/layers/helpers.py:6 needs `torch._six` (gone since torch 2.0).  The parts that
+    are NEW in this family are plain-torch files and are loaded from their own paths, unmodified:
+        ksevendet/architecture/neck/fpn.py        PANetFPN + topdown_lateral_module
+        ksevendet/architecture/head/simple_head.py Regressor, Classifier (per-level BN over shared convs)
+        ksevendet/architecture/anchors.py          Anchors (sizes_mapper / string scales)
+    The ResNet-18 trunk is the reference's architectures/retinanet.py ResNet (same BasicBlock arithmetic and
+    parameter names as backbone/resnet.py:116-176, :482-630; already pinned by e2e_r18_256), the loss the
+    reference's FocalLoss; they are wired as ksevendet.py:197-231 does (backbone -> neck -> heads -> anchors ->
+    loss) with the values of config/model/ksevendet_resnet.yaml."""
+    import yaml
+    root = '/root/reference/ksevendet/architecture/'
+    fpn_mod = _load_by_path('ref_ks_fpn', root + 'neck/fpn.py')
+    head_mod = _load_by_path('ref_ks_head', root + 'head/simple_head.py')
+    anc_mod = _load_by_path('ref_ks_anchors', root + 'anchors.py')
+    cfg = yaml.safe_load(open('/root/reference/config/model/ksevendet_resnet.yaml'))
+    assert cfg['variant'] == 'resnet18' and cfg['neck'] == 'fpn'
+    torch.manual_seed(0)
+
+    class RefKSeven(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = ref_retinanet.retinanet18(num_classes)          # trunk only: conv1 .. layer4
+            for name in ('fpn', 'regressionModel', 'classificationModel', 'anchors', 'focalLoss', 'regressBoxes', 'clipBoxes'):
+                delattr(self.backbone, name)
+            self.neck = fpn_mod.PANetFPN([128, 256, 512], in_pyramid_levels=cfg['backbone_feature_pyramid_levels'],
+                                         out_pyramid_levels=cfg['neck_feature_pyramid_levels'],
+                                         features_num=cfg['neck_config']['features_num'],
+                                         panet_buttomup=(neck == 'panet-fpn'))
+            self.anchors = anc_mod.Anchors(pyramid_levels=cfg['neck_feature_pyramid_levels'], **cfg['anchors_config'])
+            na = len(self.anchors.ratios) * len(self.anchors.scales)
+            self.regressor = head_mod.Regressor(cfg['neck_config']['features_num'], num_anchors=na,
+                                                num_pyramid_levels=5, **cfg['head_config'])
+            self.classifier = head_mod.Classifier(cfg['neck_config']['features_num'], num_anchors=na,
+                                                  num_classes=num_classes, num_pyramid_levels=5, **cfg['head_config'])
+            self.focalLoss = ref_losses.FocalLoss()
+
+        def heads(self, img):                                               # ksevendet.py:203-231
+            b = self.backbone
+            x = b.maxpool(b.relu(b.bn1(b.conv1(img))))
+            x1 = b.layer1(x)
+            x2 = b.layer2(x1)
+            x3 = b.layer3(x2)
+            x4 = b.layer4(x3)
+            feats = self.neck([x2, x3, x4])
+            return self.classifier(feats), self.regressor(feats)
+
+        def forward(self, img, ann):
+            classification, regression = self.heads(img)
+            return self.focalLoss(classification, regression, self.anchors(img), ann)
+
+    model = RefKSeven()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=gain)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.train()
+    for m in model.modules():                                               # ksevendet.py:164, :185-189: freeze_bn
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    if train_bn_heads:                                                      # per-level head BN left in train mode
+        for m in list(model.regressor.bn_modules.modules()) + list(model.classifier.bn_modules.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.train()
+    img = synth.synth_images(B, H, W, seed=1)
+    ann = synth.synth_annotations(B, H, W, num_real=8, pad_to=16, num_classes=num_classes, seed=2)
+    img_t, ann_t = torch.from_numpy(img), torch.from_numpy(ann)
+    with torch.no_grad():
+        state0 = {k: v.clone() for k, v in model.state_dict().items()}
+        cls, reg = model.heads(img_t)
+        model.load_state_dict(state0)
+    cl, rl = model(img_t, ann_t)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters()}
+    d = dict(cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(), hw=np.array([H, W]), batch=np.array(B),
+             num_classes=np.array(num_classes), gain=np.array(gain), neck=np.array(neck),
+             train_bn_heads=np.array(train_bn_heads))
+    idx = np.arange(0, cls.shape[1], 29)
+    d['head_idx'], d['cls_rows'], d['reg_rows'] = idx, cls.numpy()[:, idx, :], reg.numpy()[:, idx, :]
+    d['anchors'] = model.anchors(img_t).numpy()
+    keys = [k for k in grads if k.startswith(('neck.', 'regressor.', 'classifier.'))] + \
+           ['backbone.conv1.weight', 'backbone.layer2.0.downsample.0.weight', 'backbone.layer4.1.bn2.bias']
+    for k in keys:
+        flat = grads[k].reshape(-1)
+        sel = np.linspace(0, flat.size - 1, min(flat.size, 256)).astype(np.int64)
+        d['grad/' + k + '/idx'] = sel
+        d['grad/' + k + '/val'] = flat[sel]
+    d['grad_global_norm'] = np.array(np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in grads.values())))
+    d['state_keys'] = np.array(list(shapes.keys()))
+    d['state_shapes'] = np.array([','.join(map(str, shapes[k])) for k in shapes])
+    model.load_state_dict(state0)
+    _add_fp64_run(d, model, img_t, ann_t, lambda m, i, a: m(i, a), keys)
+    np.savez_compressed(os.path.join(OUT, 'e2e_%s.npz' % tag), **d)
+    print('e2e', tag, 'cls', cl.item(), 'reg', rl.item(), 'gnorm', d['grad_global_norm'], 'A', cls.shape[1])
+
+
 def gen_e2e_variant(kind, H, W, B, num_classes, tag, gain):
     """RetinaNetTiny (retinanet.py:486-679) / RetinaNetP45P6 (retinanet.py:722-922): three-level variants."""
     torch.manual_seed(0)
@@ -553,6 +733,14 @@ if __name__ == '__main__':
         gen_postprocess()
     if 'input' in which:
         gen_input()
+    if 'kseven' in which:
+        gen_e2e_kseven('fpn', 128, 160, 2, 12, 'kseven_r18_fpn_128x160', 0.87)
+        gen_e2e_kseven('panet-fpn', 128, 128, 2, 12, 'kseven_r18_panet_128', 0.87)
+        gen_e2e_kseven('fpn', 128, 128, 4, 12, 'kseven_r18_headbn_128', 0.87, train_bn_heads=True)
+    if 'trainbn' in which:
+        gen_e2e_trainbn(18, 128, 128, 4, 12, 'r18_trainbn_128', 0.87)
+    if 'syncbn' in which:
+        gen_syncbn()
     if 'variants' in which:
         gen_e2e_variant('tiny', 64, 96, 2, 12, 'tiny_64x96', 0.9)
         gen_e2e_variant('p45p6', 192, 288, 1, 12, 'p45p6_192x288', 0.87)
