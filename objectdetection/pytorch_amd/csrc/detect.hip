@@ -818,42 +818,66 @@ __global__ void nms_gather_boxes_kernel(const unsigned long long* __restrict__ k
 }
 
 // Upper-triangle suppression bit matrix: mask[i][jt] bit c = (IoU(box i, box jt*64 + c) > thr) for j > i, i and j in
-// descending-score order.  One block = row tile `it` (64 boxes, one per lane) x a quarter of the column tiles
-// jt >= it (the four waves of a block take every fourth of them): ~(W/4) tile pairs per block instead of one
-// 64-thread block per pair (half of which exited at once).  Words with jt < it are never written nor read.
+// descending-score order.  One block = row tile `it` (64 boxes, one per lane) x a share of the column tiles
+// jt >= it (the four waves of a block take every fourth of them).  The column box of a step is wave-uniform:
+// v_readlane -> scalar operands.  Decision without a division in the common case: q = inter * rcp(union) is within a
+// few ulp of the correctly rounded quotient; only when q lies within 1e-5 (relative) of the threshold is the IEEE
+// division (the reference arithmetic: `iou > thr` on the rounded quotient) evaluated.  The matrix is stored TILE-major,
+// mask[(it * W + jt) * 64 + lane]: the 64 words of a (row tile, column tile) pair are one contiguous 512-B store (row-major
+// put every lane's word on its own cache line: 17 M scattered 8-B stores per 46 706 boxes, ~1 ms of write amplification).
+// Pairs with jt < it are never written nor read.
+__device__ __forceinline__ float bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float4* __restrict__ sb, int K, int W,
                                                        float thr, unsigned long long* __restrict__ mask) {
     const int it = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = it * 64 + lane;
     const float4 a = i < K ? sb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float area_a = (a.z - a.x) * (a.w - a.y);
+    const float lo = thr * (1.0f - 1e-5f), hi = thr * (1.0f + 1e-5f);
     for (int jt = it + part * 4 + wv; jt < W; jt += 4 * nparts) {
         const int j0 = jt * 64;
         const float4 mine = (j0 + lane < K) ? sb[j0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float area_m = (mine.z - mine.x) * (mine.w - mine.y);
         unsigned long long bits = 0;
-        const int nc = min(64, K - j0);
-        for (int c = 0; c < nc; ++c) {                       // uniform loop: column box by lane broadcast
-            float4 b;
-            b.x = __shfl(mine.x, c, 64); b.y = __shfl(mine.y, c, 64);
-            b.z = __shfl(mine.z, c, 64); b.w = __shfl(mine.w, c, 64);
-            const float area_b = (b.z - b.x) * (b.w - b.y);
-            const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.0f);
-            const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.0f);
+        auto pair = [&](int c) {
+            const float bx = bcast(mine.x, c), by = bcast(mine.y, c), bz = bcast(mine.z, c), bw = bcast(mine.w, c);
+            const float area_b = bcast(area_m, c);
+            const float w = fmaxf(fminf(a.z, bz) - fmaxf(a.x, bx), 0.0f);
+            const float h = fmaxf(fminf(a.w, bw) - fmaxf(a.y, by), 0.0f);
             const float inter = w * h;
-            const float iou = __fdiv_rn(inter, (area_a + area_b) - inter);
-            if (j0 + c > i && iou > thr) bits |= (1ull << c);
+            const float uni = (area_a + area_b) - inter;
+            const float q = inter * __builtin_amdgcn_rcpf(uni);
+            bool over = q > hi;
+            if (!(q > hi) && !(q < lo)) over = __fdiv_rn(inter, uni) > thr;     // near the threshold (or NaN): exact
+            if (j0 + c > i && over) bits |= (1ull << c);
+        };
+        if (j0 + 64 <= K) {                                  // full column tile: fixed trip count, unrolled
+#pragma unroll 8
+            for (int c = 0; c < 64; ++c) pair(c);
+        } else {
+            for (int c = 0; c < K - j0; ++c) pair(c);
         }
-        if (i < K) mask[(size_t)i * W + jt] = bits;
+        mask[((size_t)it * W + jt) * 64 + lane] = i < K ? bits : 0ull;      // (rows >= K are never read)
     }
 }
 
 // Greedy sweep in steps of SW_S = 1024 boxes (SW_T = 16 mask words).  The serial part of NMS is cheap when the
-// bits are on chip (~10 cycles per box); what made a tile-by-tile sweep slow is one dependent HBM round trip per
-// 64 boxes.  Per step: `nms_resolve_kernel` (ONE block) stages the 1024 x 1024 diagonal bit block in LDS and one
-// wave walks the boxes in order against the running `removed` words; `nms_propagate_kernel` (many blocks) then
-// ORs the mask rows of the step's kept boxes into the `removed` words of all later boxes at chip bandwidth.
-constexpr int SW_S = 1024, SW_T = 16, SW_LD = 17;          // LDS row stride in words (odd: conflict-free row writes)
+// bits are on chip (a scalar bit test per suppressed box, ~30 cycles per kept one); what made a tile-by-tile sweep
+// slow is one dependent HBM round trip per 64 boxes.  Per step: `nms_resolve_kernel` (ONE block) stages the
+// 1024 x 1024 diagonal bit block in LDS (coalesced: 16 lanes per row) and one wave walks the boxes in order against
+// the running `removed` words, all decisions in scalar registers; `nms_propagate_kernel` (many blocks) then ORs the
+// mask rows of the step's kept boxes into the `removed` words of all later boxes.
+constexpr int SW_S = 1024, SW_T = 16, SW_LD = 17;          // LDS row stride in words (odd: conflict-free)
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
 
 __global__ __launch_bounds__(1024) void nms_resolve_kernel(const unsigned long long* __restrict__ mask,
                                                            const int32_t* __restrict__ sorted_idx, int K, int W, int step,
@@ -865,13 +889,12 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(const unsigned long l
     const int tid = threadIdx.x, lane = tid & 63;
     const int t0 = step * SW_T, r0 = step * SW_S;
     const int nr = min(SW_S, K - r0), nt = min(SW_T, W - t0);
-    {                                                          // row tid of the diagonal block (upper triangle only)
-        const int own = tid >> 6;
-        for (int w = 0; w < SW_T; ++w) {
-            unsigned long long v = 0ull;
-            if (tid < nr && w < nt && w >= own) v = mask[(size_t)(r0 + tid) * W + t0 + w];
-            diag[tid * SW_LD + w] = v;
-        }
+#pragma unroll 4
+    for (int ti = 0; ti < SW_T; ++ti) {                        // a wave reads one (row tile, word) pair: 512 B contiguous
+        const int w = tid >> 6, row = ti * 64 + lane;
+        unsigned long long v = 0ull;
+        if (row < nr && w < nt && w >= ti) v = mask[((size_t)(t0 + ti) * W + t0 + w) * 64 + lane];
+        diag[row * SW_LD + w] = v;
     }
     __syncthreads();
     if (tid < 64) {
@@ -879,16 +902,19 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(const unsigned long l
         unsigned long long rem = (lane < nt) ? removed[t0 + lane] : ~0ull;       // lanes 0..15: this step's words
         unsigned long long kept = 0ull;
         for (int wd = 0; wd < nt; ++wd) {
-            unsigned long long cur = __shfl(rem, wd, 64);                          // word of the 64 boxes being walked
+            unsigned long long cur = readlane64(rem, wd);                          // scalar: the 64 boxes being walked
             const int nb = min(64, nr - wd * 64);
             unsigned long long kw = 0ull;
-            for (int bit = 0; bit < nb; ++bit) {
-                const unsigned long long row = diag[(wd * 64 + bit) * SW_LD + l16];   // (issued ahead of the decision)
-                if (!((cur >> bit) & 1ull)) {                                       // uniform
-                    kw |= 1ull << bit;
-                    rem |= row;
-                    cur |= __shfl(row, wd, 64);
-                }
+            const unsigned long long* rowp = diag + (wd * 64) * SW_LD + l16;
+            const unsigned long long valid = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+            unsigned long long alive = ~cur & valid;                                // scalar; suppressed boxes cost nothing
+            while (alive) {
+                const int bit = __ffsll((long long)alive) - 1;                      // next box that survived so far: kept
+                kw |= 1ull << bit;
+                const unsigned long long row = rowp[bit * SW_LD];
+                rem |= row;
+                cur |= readlane64(row, wd);
+                alive = ~cur & valid & ~((2ull << bit) - 1ull);                     // later boxes of this word still alive
             }
             if (lane == wd) kept = kw;
         }
@@ -911,32 +937,27 @@ __global__ __launch_bounds__(1024) void nms_resolve_kernel(const unsigned long l
     if (tid == 0) *d_num_keep = base + total;
 }
 
+// block = (64 later words) x (4 row groups); blockIdx.y = one of the step's 16 kept words: the rows of that word's kept
+// boxes are OR-ed by 4 threads per removed word (<= 16 rows each, all loads independent) and merged with one atomicOr.
 __global__ __launch_bounds__(256) void nms_propagate_kernel(const unsigned long long* __restrict__ mask, int K, int W,
                                                             int step, const unsigned long long* __restrict__ kept_bits,
                                                             unsigned long long* __restrict__ removed) {
-    const int t0 = step * SW_T, r0 = step * SW_S;
-    const int w = t0 + SW_T + blockIdx.x * 256 + threadIdx.x;
-    if (w >= W) return;
-    unsigned long long acc = removed[w];
-    const int nt = min(SW_T, W - t0);
-    for (int kwi = 0; kwi < nt; ++kwi) {
-        unsigned long long k2 = kept_bits[t0 + kwi];                                // uniform
-        const unsigned long long* rowbase = mask + (size_t)(r0 + kwi * 64) * W + w;
-        while (k2) {                                                                // up to 4 independent loads in flight
-            int r[4];
-            int n = 0;
+    const int t0 = step * SW_T;
+    const int kwi = blockIdx.y;
+    if (t0 + kwi >= W) return;
+    const unsigned long long kb = kept_bits[t0 + kwi];                             // uniform
+    if (kb == 0ull) return;
+    const int w = t0 + SW_T + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int grp = threadIdx.x >> 6;                                               // rows 16 grp .. 16 grp + 15 of the word
+    unsigned long long sub = (kb >> (16 * grp)) & 0xffffull;
+    if (w >= W || sub == 0ull) return;
+    // tile-major mask: the 16 rows of this group are 128 contiguous bytes of the (row tile, word) pair
+    const unsigned long long* rowbase = mask + ((size_t)(t0 + kwi) * W + w) * 64 + 16 * grp;
+    unsigned long long acc = 0ull;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                r[u] = 0;
-                if (k2) { r[u] = __ffsll((long long)k2) - 1; k2 &= k2 - 1; n = u + 1; }
-            }
-            unsigned long long v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = u < n ? rowbase[(size_t)r[u] * W] : 0ull;
-            acc |= (v[0] | v[1]) | (v[2] | v[3]);
-        }
-    }
-    removed[w] = acc;
+    for (int r = 0; r < 16; ++r)
+        if ((sub >> r) & 1ull) acc |= rowbase[r];
+    if (acc) atomicOr(removed + w, acc);
 }
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -945,7 +966,7 @@ extern "C" int mi355_nms_workspace_bytes(int K, int64_t* bytes) {
     MI355_REQUIRE(K >= 0 && bytes, "nms_workspace_bytes: bad args");
     int64_t K2 = next_pow2(K < SORT_CHUNK ? SORT_CHUNK : K);
     int64_t W = cdiv(K, 64);
-    *bytes = K2 * 8 + (int64_t)K * 16 + (int64_t)K * 4 + 64 + (int64_t)K * W * 8 + 256 + 2 * (W * 8 + 64);
+    *bytes = K2 * 8 + (int64_t)K * 16 + (int64_t)K * 4 + 64 + W * W * 64 * 8 + 256 + 2 * (W * 8 + 64);
     return MI355_OK;
 }
 
@@ -970,7 +991,7 @@ extern "C" int mi355_nms(const float* boxes, const float* scores, int K, float i
     unsigned long long* keys = (unsigned long long*)p;  p += (int64_t)K2 * 8;
     float4* sboxes = (float4*)p;                        p += (int64_t)K * 16;
     int32_t* sidx = (int32_t*)p;                        p += (((int64_t)K * 4 + 63) / 64) * 64;
-    unsigned long long* mask = (unsigned long long*)p;              p += (int64_t)K * W * 8;
+    unsigned long long* mask = (unsigned long long*)p;              p += (int64_t)W * W * 64 * 8;
     unsigned long long* removed = (unsigned long long*)p;           p += (((int64_t)W * 8 + 63) / 64) * 64;
     unsigned long long* kept_bits = (unsigned long long*)p;
 
@@ -998,7 +1019,7 @@ extern "C" int mi355_nms(const float* boxes, const float* scores, int K, float i
                            kept_bits, keep_out, d_num_keep);
         const int rest = W - (step + 1) * SW_T;
         if (rest > 0)
-            hipLaunchKernelGGL(nms_propagate_kernel, dim3((unsigned)cdiv(rest, 256)), dim3(256), 0, st, mask, K, W, step,
+            hipLaunchKernelGGL(nms_propagate_kernel, dim3((unsigned)cdiv(rest, 64), SW_T), dim3(256), 0, st, mask, K, W, step,
                                kept_bits, removed);
     }
     return check_launch("nms");
