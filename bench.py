@@ -117,7 +117,8 @@ def conv_flops(plan):
     return fwd, fwd + dgrad + fwd     # (forward, training = fwd + dgrad + wgrad)
 
 
-CONV_STEPS = ('mi355_conv_gather', 'mi355_conv_gather_splitk', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_slabs')
+CONV_STEPS = ('mi355_conv_gather', 'mi355_conv_gather_splitk', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_slabs',
+              'mi355_conv_wgrad_multi')
 
 
 def conv_bytes(plan):
@@ -129,7 +130,8 @@ def conv_bytes(plan):
             continue
         L = args[0]._obj
         gather = name.startswith('mi355_conv_gather')
-        total += 2.0 * L.K * L.T * L.prob[0].C * (1 if gather else 2)      # weights / one dW tile set (fp32 = 2 x 2 B)
+        # weights / one dW tile set (fp32 = 2 x 2 B); a multi-layer wgrad launch writes one per problem (= per layer)
+        total += 2.0 * L.K * L.T * L.prob[0].C * (1 if gather else 2) * (L.nprob if name.endswith('_multi') else 1)
         for i in range(L.nprob):
             p = L.prob[i]
             M = p.N * p.P * p.Q
@@ -146,7 +148,7 @@ def conv_bytes(plan):
 def conv_launch_bytes(L, name):
     """One conv launch of `conv_bytes`: every operand read once, every result written once."""
     gather = name.startswith('mi355_conv_gather')
-    total = 2.0 * L.K * L.T * L.prob[0].C * (1 if gather else 2)
+    total = 2.0 * L.K * L.T * L.prob[0].C * (1 if gather else 2) * (L.nprob if name.endswith('_multi') else 1)
     for i in range(L.nprob):
         p = L.prob[i]
         M = p.N * p.P * p.Q

@@ -83,6 +83,13 @@ int mi355_conv_wgrad_colsum(const Mi355ConvLaunch* launch, float* dw, float* col
 int mi355_conv_wgrad_num_slabs(const Mi355ConvLaunch* launch, int split_rows, int* nslabs);
 int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* ws, int64_t slab_stride, int max_slabs,
                            float* colsum, int split_rows, void* stream);
+/* Multi-LAYER form: the problems are the same-shape convs of DIFFERENT layers (the identical bottleneck blocks of a
+ * ResNet stage: their weight gradients are independent leaves of the backward pass, and each alone is a 20-40 us
+ * launch that cannot fill 256 CUs).  Problem i writes its pixel chunks into slabs 0 .. of its OWN workspace ws[i]
+ * (capacity max_slabs[i]) and its dy column sums into colsum[i] (may be NULL); K, T, C and the conv geometry are
+ * those of the launch, as above.  Slab mode only. */
+int mi355_conv_wgrad_multi(const Mi355ConvLaunch* launch, float* const* ws, int64_t slab_stride,
+                           const int* max_slabs, float* const* colsum, int split_rows, void* stream);
 /* out[i] (+)= sum_s ws[s*slab_stride + i], i < n (n, slab_stride multiples of 4; 16-B aligned) */
 int mi355_slab_reduce(const float* ws, int nslabs, int64_t slab_stride, int64_t n, float* out,
                       int accumulate, void* stream);

@@ -43,12 +43,15 @@ struct WProb {
     int chunk_begin;
     int in_sN, dy_sN;
     FastDiv dPQ, dQ;
+    // where this problem's partial tiles go: slab `local chunk` of its own workspace (slab mode), or the gradient
+    // itself (atomic mode).  Problems of a shared-weight launch point into ONE workspace (slabs chunk_begin ..);
+    // problems of a multi-layer launch (same shape, different layers) each have their own.
+    float* dw;
+    float* colsum;
 };
 
 struct WLaunch {
     WProb p[MI355_CONV_MAX_PROBLEMS];
-    float* dw;
-    float* colsum;
     long long slab_stride;      // > 0: plain stores into slab `chunk` (dw + chunk*slab_stride), reduced later
     int nprob, K, T, k_tiles, c_tiles, ntaps, split_rows;
     // grouped launches: chunks sorted by length (longest first), so that the short chunks of the small
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
         m_begin = (chunk - P.chunk_begin) * L.split_rows;
     }
     const int m_end = min(P.M, m_begin + L.split_rows);
+    const int lchunk_id = m_begin / L.split_rows;       // slab of this block inside the problem's workspace
     const int k0 = k_tile * TK, c0 = c_tile * TC;
 
     const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(P.in, (unsigned)P.in_bytes);
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
 
     // column sums of dy (bias / BN-beta gradient): only the blocks owning (tap 0, c-tile 0) and
     // only their wc == 0 waves (the other column-waves hold the same dy fragments)
-    const bool do_colsum = L.colsum != nullptr && c_tile == 0 && tap == 0 && wc == 0;
+    const bool do_colsum = P.colsum != nullptr && c_tile == 0 && tap == 0 && wc == 0;
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
     const int nsteps = (m_end - m_begin + RMS - 1) / RMS;
     fill(0);
@@ -307,8 +311,8 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
             const int k = k0 + wk * 64 + t * 16 + (lane & 15);
             if (lane < 16 && k < L.K) {
                 const float v = cs_v[t] + (NG > 1 ? s_cs[wk * 64 + t * 16 + lane] : 0.0f);
-                if (L.slab_stride > 0) L.colsum[(long long)chunk * L.K + k] = v;   // slab mode: [chunk][K]
-                else atomicAdd(L.colsum + k, v);
+                if (L.slab_stride > 0) P.colsum[(long long)lchunk_id * L.K + k] = v;   // slab mode: [chunk][K]
+                else atomicAdd(P.colsum + k, v);
             }
         }
     }
@@ -334,9 +338,9 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
 #pragma unroll
         for (int h = 0; h < 2; ++h)
             if (coff[h] >= 0) {
-                float* dst = L.dw + k * wrow + coff[h];
+                float* dst = P.dw + k * wrow + coff[h];
                 const float v = epi[rr * EPI_LD + h * 64 + lane];
-                if (L.slab_stride > 0) dst[(long long)chunk * L.slab_stride] = v;   // deterministic split-K
+                if (L.slab_stride > 0) dst[(long long)lchunk_id * L.slab_stride] = v;   // deterministic split-K
                 else atomicAdd(dst, v);
             }
     }
@@ -386,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
         m_begin = (chunk - P.chunk_begin) * L.split_rows;
     }
     const int m_end = min(P.M, m_begin + L.split_rows);
+    const int lchunk_id = m_begin / L.split_rows;
     const int k0 = k_tile * TK, c0 = c_tile * R3_TC;
     const int dh = P.dh0 + kr;                          // (dhs == 1)
 
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
             }
         }
 
-    const bool do_colsum = L.colsum != nullptr && c_tile == 0 && kr == 0 && wc == 0;
+    const bool do_colsum = P.colsum != nullptr && c_tile == 0 && kr == 0 && wc == 0;
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
     const int nsteps = (m_end - m_begin + RM - 1) / RM;
     fill(0);
@@ -546,8 +551,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
             v += __shfl_xor(v, 32, 64);
             const int k = k0 + wk * 64 + t * 16 + (lane & 15);
             if (lane < 16 && k < L.K) {
-                if (L.slab_stride > 0) L.colsum[(long long)chunk * L.K + k] = v;
-                else atomicAdd(L.colsum + k, v);
+                if (L.slab_stride > 0) P.colsum[(long long)lchunk_id * L.K + k] = v;
+                else atomicAdd(P.colsum + k, v);
             }
         }
     }
@@ -569,9 +574,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
         for (int rr = wv; rr < TK; rr += 4) {
             const int k = k0 + rr;
             if (k >= L.K) break;
-            float* dst = L.dw + k * wrow + coff;
+            float* dst = P.dw + k * wrow + coff;
             const float v = epi[rr * R3_EPI_LD + lane];
-            if (L.slab_stride > 0) dst[(long long)chunk * L.slab_stride] = v;
+            if (L.slab_stride > 0) dst[(long long)lchunk_id * L.slab_stride] = v;
             else atomicAdd(dst, v);
         }
         __syncthreads();
@@ -632,10 +637,24 @@ extern "C" int mi355_conv_wgrad_num_slabs(const Mi355ConvLaunch* launch, int spl
     return MI355_OK;
 }
 
+static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t slab_stride, const int* max_slabs,
+                        float* const* colsums, bool multi, int split_rows, void* stream);
+
 extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, int64_t slab_stride,
                                       int max_slabs, float* colsum, int split_rows, void* stream) {
     MI355_REQUIRE(launch && dw, "conv_wgrad: null argument");
-    const Mi355ConvLaunch& in = *launch;
+    return wgrad_launch(*launch, &dw, slab_stride, &max_slabs, &colsum, false, split_rows, stream);
+}
+
+extern "C" int mi355_conv_wgrad_multi(const Mi355ConvLaunch* launch, float* const* ws, int64_t slab_stride,
+                                      const int* max_slabs, float* const* colsum, int split_rows, void* stream) {
+    MI355_REQUIRE(launch && ws && max_slabs && colsum && slab_stride > 0, "conv_wgrad_multi: null argument / slab mode only");
+    for (int i = 0; i < launch->nprob; ++i) MI355_REQUIRE(ws[i], "conv_wgrad_multi: problem %d has no workspace", i);
+    return wgrad_launch(*launch, ws, slab_stride, max_slabs, colsum, true, split_rows, stream);
+}
+
+static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t slab_stride, const int* max_slabs,
+                        float* const* colsums, bool multi, int split_rows, void* stream) {
     MI355_REQUIRE(in.nprob >= 1 && in.nprob <= MI355_CONV_MAX_PROBLEMS, "conv_wgrad: nprob");
     MI355_REQUIRE(in.K > 0 && in.K % 8 == 0 && in.T > 0, "conv_wgrad: K must be a positive multiple of 8");
     MI355_REQUIRE(split_rows > 0 && split_rows % RM == 0, "conv_wgrad: split_rows must be a multiple of 64");
@@ -673,7 +692,16 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
         d.dPQ = make_fastdiv((unsigned)(s.P * s.Q));
         d.dQ = make_fastdiv((unsigned)s.Q);
         d.chunk_begin = chunks;
-        chunks += (int)cdiv(M, split_rows);
+        const int mine = (int)cdiv(M, split_rows);
+        if (multi) {                                   // one workspace per problem (= per layer), slabs 0 .. mine-1
+            MI355_REQUIRE(mine <= max_slabs[i], "conv_wgrad_multi: problem %d: %d slabs > workspace for %d", i, mine, max_slabs[i]);
+            d.dw = dws[i];
+            d.colsum = colsums[i];
+        } else {                                       // shared weight: one workspace, this problem's slabs start at `chunks`
+            d.dw = dws[0] + (slab_stride > 0 ? (long long)chunks * slab_stride : 0);
+            d.colsum = colsums[0] ? colsums[0] + (slab_stride > 0 ? (long long)chunks * in.K : 0) : nullptr;
+        }
+        chunks += mine;
     }
     if (ntaps == 0) return MI355_OK;
     // row-of-taps kernel: 3x3 / stride 1 / same, C % 64 == 0, image width a power of two <= 64
@@ -704,10 +732,8 @@ extern "C" int mi355_conv_wgrad_slabs(const Mi355ConvLaunch* launch, float* dw, 
             }
         L.nsorted = n;
     }
-    L.dw = dw;
-    L.colsum = colsum;
     L.slab_stride = slab_stride;
-    MI355_REQUIRE(slab_stride == 0 || chunks <= max_slabs, "conv_wgrad_slabs: %d slabs > workspace for %d", chunks, max_slabs);
+    MI355_REQUIRE(multi || slab_stride == 0 || chunks <= max_slabs[0], "conv_wgrad_slabs: %d slabs > workspace for %d", chunks, max_slabs[0]);
     L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.ntaps = ntaps; L.split_rows = split_rows;
     const bool flat = C < TC && !row3;
     L.k_tiles = (int)cdiv(in.K, TK);

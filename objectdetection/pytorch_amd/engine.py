@@ -121,6 +121,7 @@ class RetinaPlan(object):
         # their .grad None, so autograd gets None and the flat optimizer skips them (train.py:320-321)
         self.unused_param_ids = set()
         self.bn_saved = {}
+        self._pending_wgrads, self._grouping_wgrads = {}, False
         self._meta()
         if H % self.input_multiple or W % self.input_multiple:
             # the reference's FPN / BiFPN (nn.Upsample x2 + add, retinanet.py:52-61,
@@ -167,7 +168,7 @@ class RetinaPlan(object):
         if getattr(self, '_mark_side', False):
             self._side_ids.add(id(args))
 
-    SIDE_STEPS = ('mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_slabs_f32')
+    SIDE_STEPS = ('mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_slabs_f32', 'mi355_conv_wgrad_multi')
 
     def _run(self, steps, stream):
         """Launch `steps` on `stream`.  With the side stream enabled (MI355_SIDE_STREAM=1) the weight-gradient
@@ -428,6 +429,54 @@ class RetinaPlan(object):
         self._step(self.bwd_steps, 'mi355_conv_wgrad_slabs', ctypes.byref(L), ptr(spec.G), c_i64(slab),
                    c_int(nslabs), ptr(spec.colsum if colsum else None), c_int(split))
 
+    # -- same-shape weight gradients of a stage as ONE launch ---------------------------------------------------------
+    # The identical bottleneck / basic blocks of a ResNet stage produce weight gradients of the same shape that are
+    # independent leaves of the backward pass; alone each is a 25-50 us launch that cannot fill 256 CUs (layer3 conv2
+    # of R50 512^2 bs16: 44 us = 437 TFLOP/s alone, 27 us per block = 724 TFLOP/s when five blocks share a launch:
+    # tools/bench_wgrad_group.py).  conv_bwd defers them; the stage's end (or five of a kind) flushes a group.
+    def _defer_wgrad(self, pr, spec, rows, x, dy):
+        # (a launch needs one K, C and tap geometry; image sizes may differ per problem, as in the five-level head launches)
+        key = (spec.Kpad, spec.Cpad, spec.R, spec.S, spec.stride, spec.pad)
+        group = self._pending_wgrads.setdefault(key, [])
+        group.append((pr, spec, rows))
+        if len(group) == ops_conv.MAX_PROBLEMS:
+            self._flush_wgrads(key)
+
+    def _flush_wgrads(self, key=None):
+        for k in ([key] if key is not None else list(self._pending_wgrads)):
+            group = self._pending_wgrads.pop(k, [])
+            if len(group) == 1:
+                self._wgrad([group[0][0]], group[0][1], group[0][2])
+            elif group:
+                self._wgrad_multi(group)
+
+    def _wgrad_multi(self, group):
+        spec0 = group[0][1]
+        problems = [g[0] for g in group]
+        L = ConvLaunch()
+        for j, pr in enumerate(problems):
+            L.prob[j] = pr
+        L.nprob, L.K, L.T = len(problems), spec0.Kpad, spec0.T
+        slab = spec0.Kpad * spec0.T * spec0.Cpad
+        tiles = ops_conv.wgrad_tiles(spec0.Kpad, spec0.Cpad, spec0.T, problems)
+        split = pick_split_rows(sum(g[2] for g in group), tiles,
+                                target_blocks=int(os.environ.get('MI355_WG_BLOCKS', '512')),
+                                min_rows=int(os.environ.get('MI355_WG_MINROWS', '1024')),
+                                granule=int(os.environ.get('MI355_WG_GRANULE', '64')))
+        n = len(group)
+        ws, cs, cap = (c_vp * n)(), (c_vp * n)(), (c_int * n)()
+        for j, (pr, spec, rows) in enumerate(group):
+            nslabs = -(-rows // split)
+            if spec.G is None or spec.nslabs != nslabs:
+                spec.nslabs = nslabs
+                spec.G = self.new((nslabs, slab), torch.float32)
+                spec.colsum = self.new((nslabs, spec.Kpad), torch.float32, zero=True)
+            ws[j], cs[j], cap[j] = spec.G.data_ptr(), spec.colsum.data_ptr(), nslabs
+            spec._wgrad_launch = L
+            spec._wgrad_end = len(self.bwd_steps) + 1
+        self.keep.append((L, ws, cs, cap))
+        self._step(self.bwd_steps, 'mi355_conv_wgrad_multi', ctypes.byref(L), ws, c_i64(slab), cap, cs, c_int(split))
+
     def conv(self, spec, x, act=ACT_NONE, addend=None, add_shift=0):
         N, H, W, C = x.shape
         assert C == spec.Cpad, (spec.name, C, spec.Cpad)
@@ -533,7 +582,10 @@ class RetinaPlan(object):
         if spec.bn_train:                                  # dy is the gradient of the BN output: through the BN first
             dy = self.bn_bwd(spec, dy)
         pr = fwd_problem(x, dy.data_ptr(), spec.R, spec.S, spec.stride, (pt, pl), K=spec.Kpad, out_size=(P, Q))
-        self._wgrad([pr], spec, N * pr.P * pr.Q)          # + fused column sums (bias / beta grads)
+        if self._grouping_wgrads:
+            self._defer_wgrad(pr, spec, N * pr.P * pr.Q, x, dy)
+        else:
+            self._wgrad([pr], spec, N * pr.P * pr.Q)      # + fused column sums (bias / beta grads)
         if not dgrad:
             return None
         if dx is None:
@@ -670,9 +722,16 @@ class RetinaPlan(object):
         self.fwd_launches.append((spec, [(x.shape[0], x.shape[1], x.shape[2]) for x in xs]))
 
     # ------------------------------------------------------------------ backward
+    def _wgrad_grouping_ok(self):
+        return (os.environ.get('MI355_WG_GROUP', '1') == '1' and self.deterministic and self.prec == 'bf16' and
+                type(self).conv_bwd is RetinaPlan.conv_bwd)
+
     def _build_backward(self):
         g_feat = self._heads_bwd()
+        self._grouping_wgrads = self._wgrad_grouping_ok()      # the three 3x3 smoothing convs of the pyramid share a launch
         g, extra = self._fpn_bwd(g_feat)
+        self._grouping_wgrads = False
+        self._flush_wgrads()
         g = self._stages_bwd(g, extra)
         self._stem_bwd(g)
         self._build_param_grads()
@@ -713,8 +772,10 @@ class RetinaPlan(object):
 
     def _stages_bwd(self, g, extra):
         """Backbone, last block first.  g = gradient w.r.t. the block output's pre-ReLU sum."""
+        group = self._wgrad_grouping_ok()
         for i in range(len(self.blocks) - 1, -1, -1):
             rec = self.blocks[i]
+            self._grouping_wgrads = group
             x = rec['x']
             first_block = (i == 0)
             x_extra = None
@@ -735,6 +796,9 @@ class RetinaPlan(object):
                 assert x_extra is None
                 res_g = g
             g = self.conv_bwd(last, x, g_a, addend=res_g, mask=mask_x)
+            self._grouping_wgrads = False
+            if i == 0 or self.blocks[i - 1]['stage'] != rec['stage']:
+                self._flush_wgrads()                       # the stage is done: its deferred weight gradients, grouped
         return g
 
     def _stem_bwd(self, g):

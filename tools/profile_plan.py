@@ -19,7 +19,7 @@ st = torch.cuda.current_stream()
 rows = []
 for phase, steps in (('fwd', plan.fwd_steps), ('bwd', plan.bwd_steps)):
     for fn, args, name in steps:
-        if name not in ('mi355_conv_gather', 'mi355_conv_gather_splitk', 'mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum'):
+        if name not in ('mi355_conv_gather', 'mi355_conv_gather_splitk', 'mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_multi'):
             continue
         L = ctypes.cast(args[0], ctypes.POINTER(ops_conv.ConvLaunch)).contents if False else args[0]._obj
         flops = 0.0

@@ -11,10 +11,9 @@ for line in sys.stdin:
 "
 }
 run A=0
+run MI355_WG_GROUP=0
 run MI355_SIDE_STREAMS=2
-run MI355_WG_BLOCKS=384
-run MI355_WG_BLOCKS=768
-run MI355_WG_MINROWS=2048
 run MI355_SEG_MB=64
-run MI355_SIDE_STREAMS=2 MI355_WG_BLOCKS=768
+run MI355_SIDE_STREAMS=2 MI355_SEG_MB=64
+run MI355_SEG_MB=1000
 run A=1
