@@ -117,6 +117,34 @@ int mi355_maxpool_same_fwd(const void* in, void* out, int8_t* idx, int N, int H,
 int mi355_maxpool_same_bwd(const void* gout, const int8_t* idx, void* gin, int N, int H, int W, int C,
                            int accumulate, void* stream);
 
+/* ---- fp32-accurate mode (MI355_CONV_PRECISION=fp32 / model.precision = 'fp32') ----------------------------------
+ * The same entry points with every activation / gradient tensor fp32 (the reference trains in fp32, train.py:259-321):
+ * identical arguments and arithmetic, exact expf / division swish instead of the v_exp / v_rcp forms that are only
+ * accurate to the bf16 rounding.  The 1x1 convs of this mode run on mi355_conv_gather_f32 (mi355det_conv.h). */
+int mi355_dwconv_fwd_f32(const void* in, int in_swish, const float* w_t, const float* bias, void* out, int N, int H,
+                         int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q, void* stream);
+int mi355_dwconv_dgrad_f32(const void* dy, const float* w_t, void* dx, const void* zin, int N, int H, int W, int C,
+                           int k, int stride, int pad_t, int pad_l, int P, int Q, int accumulate, void* stream);
+int mi355_dwconv_wgrad_f32(const void* x, int in_swish, const void* dy, float* dw_t, float* colsum, int N, int H, int W,
+                           int C, int k, int stride, int pad_t, int pad_l, int P, int Q, void* stream);
+int mi355_se_pool_f32(const void* z, int in_swish, float* pool_partial, int N, int HW, int C, void* stream);
+int mi355_se_scale_f32(const void* z, const float* gate, void* u, int N, int HW, int C, void* stream);
+int mi355_se_bwd_reduce_f32(const void* gu, const void* z, float* ggate_partial, int N, int HW, int C, void* stream);
+int mi355_se_bwd_apply_f32(const void* gu, const void* z, const float* gate, const float* gpool, void* gz, int N, int HW,
+                           int C, void* stream);
+int mi355_bifpn_node_fwd_f32(const void* in0, const void* in1, int up1, const void* in2, const float* w, void* z, int N,
+                             int H, int W, int C, void* stream);
+int mi355_bifpn_node_wgrad_f32(const void* gz, const void* in0, const void* in1, int up1, const void* in2, float* gw,
+                               int N, int H, int W, int C, void* stream);
+int mi355_axpy_f32(const void* src, const float* w, int wi, void* dst, int64_t n, int accumulate, void* stream);
+int mi355_drop_connect_f32(const void* src, const float* u, float keep, const void* addend, void* dst, int N,
+                           int64_t per_image, void* stream);
+int mi355_upsample_bwd_axpy_f32(const void* src, const float* w, int wi, void* dst, int N, int H, int W, int C,
+                                int accumulate, void* stream);
+int mi355_maxpool_same_fwd_f32(const void* in, void* out, int8_t* idx, int N, int H, int W, int C, void* stream);
+int mi355_maxpool_same_bwd_f32(const void* gout, const int8_t* idx, void* gin, int N, int H, int W, int C,
+                               int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -208,6 +208,9 @@ class EfficientDet(nn.Module):
         gp = self.backbone_net.model._global_params
         dc = bool(getattr(gp, 'drop_connect_rate', None)) and any(b.training for b in self.backbone_net.model._blocks)
         key = (img.shape[0], img.shape[2], img.shape[3], img.device.index, dc)
+        from .. import engine
+        if engine.precision_of(self) != 'bf16':          # `model.precision = 'fp32'`: the fp32-accurate plan
+            key = key + (engine.precision_of(self),)
         from .retinanet import _cached_plan
 
         def build():

@@ -40,6 +40,25 @@ __device__ __forceinline__ void store8(unsigned short* p, const float v[8]) {
     for (int e = 0; e < 8; ++e) t[e] = (short)f32_to_bf16_rn(v[e]);
     *reinterpret_cast<s8v*>(p) = t;
 }
+// fp32-accurate mode (MI355_CONV_PRECISION=fp32, RetinaPlan.prec): the generic (untiled) kernels below are templates
+// over the storage type; fp32 tensors take the exact expf / IEEE-division swish
+__device__ __forceinline__ void load8(const float* p, float v[8]) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(float* p, const float v[8]) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <typename T> struct Act;
+template <> struct Act<unsigned short> {
+    static __device__ __forceinline__ float sw(float x) { return swishf(x); }
+    static __device__ __forceinline__ float dsw(float x) { return dswishf(x); }
+};
+template <> struct Act<float> {
+    static __device__ __forceinline__ float sw(float x) { return swishf_exact(x); }
+    static __device__ __forceinline__ float dsw(float x) { return dswishf_exact(x); }
+};
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -85,9 +104,9 @@ extern "C" int mi355_dw_prep_table(const Mi355DwPrepDesc* table, int n, int max_
     return check_launch("dw_prep_table_kernel");
 }
 
-template <bool SWISH>
-__global__ void dwconv_fwd_kernel(const unsigned short* __restrict__ in, const float* __restrict__ w_t,
-                                  const float* __restrict__ bias, unsigned short* __restrict__ out, int N, int H,
+template <typename T, bool SWISH>
+__global__ void dwconv_fwd_kernel(const T* __restrict__ in, const float* __restrict__ w_t,
+                                  const float* __restrict__ bias, T* __restrict__ out, int N, int H,
                                   int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q) {
     const int c8n = C >> 3;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,7 +129,7 @@ __global__ void dwconv_fwd_kernel(const unsigned short* __restrict__ in, const f
             load8(in + (((long long)n * H + h) * W + w) * C + c8 * 8, x);
             const float* wt = w_t + (a * k + b) * C + c8 * 8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += (SWISH ? swishf(x[e]) : x[e]) * wt[e];
+            for (int e = 0; e < 8; ++e) acc[e] += (SWISH ? Act<T>::sw(x[e]) : x[e]) * wt[e];
         }
     }
     store8(out + t * 8, acc);
@@ -316,18 +335,19 @@ extern "C" int mi355_dwconv_fwd(const void* in, int in_swish, const float* w_t, 
     }
     const long long total = (long long)N * P * Q * (C / 8);
     if (in_swish)
-        hipLaunchKernelGGL(dwconv_fwd_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((dwconv_fwd_kernel<unsigned short, true>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                            (const unsigned short*)in, w_t, bias, (unsigned short*)out, N, H, W, C, k, stride,
                            pad_t, pad_l, P, Q);
     else
-        hipLaunchKernelGGL(dwconv_fwd_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((dwconv_fwd_kernel<unsigned short, false>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                            (const unsigned short*)in, w_t, bias, (unsigned short*)out, N, H, W, C, k, stride,
                            pad_t, pad_l, P, Q);
     return check_launch("dwconv_fwd_kernel");
 }
 
-__global__ void dwconv_dgrad_kernel(const unsigned short* __restrict__ dy, const float* __restrict__ w_t,
-                                    unsigned short* __restrict__ dx, const unsigned short* __restrict__ zin, int N,
+template <typename T>
+__global__ void dwconv_dgrad_kernel(const T* __restrict__ dy, const float* __restrict__ w_t,
+                                    T* __restrict__ dx, const T* __restrict__ zin, int N,
                                     int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
                                     int accumulate) {
     const int c8n = C >> 3;
@@ -360,7 +380,7 @@ __global__ void dwconv_dgrad_kernel(const unsigned short* __restrict__ dy, const
         float z[8];
         load8(zin + t * 8, z);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] *= dswishf(z[e]);
+        for (int e = 0; e < 8; ++e) acc[e] *= Act<T>::dsw(z[e]);
     }
     if (accumulate) {
         float o[8];
@@ -466,7 +486,7 @@ extern "C" int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, co
         return check_launch("dwconv_dgrad_s2_kernel");
     }
     const long long total = (long long)N * H * W * (C / 8);
-    hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(dwconv_dgrad_kernel<unsigned short>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)dy, w_t, (unsigned short*)dx, (const unsigned short*)zin, N, H, W, C,
                        k, stride, pad_t, pad_l, P, Q, accumulate);
     return check_launch("dwconv_dgrad_kernel");
@@ -476,16 +496,16 @@ extern "C" int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, co
 // lanes are reduced through LDS so that a block issues ONE atomic per (tap, channel): contention on
 // the tiny dw_t tensor is the number of row chunks (~100), not the number of threads.
 constexpr int DW_IPB = 32, DW_PL = 8;
-template <bool SWISH>
+template <typename T, bool SWISH>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(
-    const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy, float* __restrict__ dw_t,
+    const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw_t,
     float* __restrict__ colsum, int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
     int rows_per_block) {
     __shared__ float s_acc[DW_PL][DW_IPB][9];
-    const int c8n = C >> 3, T = k * k;
+    const int c8n = C >> 3, NT = k * k;
     const int il = threadIdx.x % DW_IPB, pl = threadIdx.x / DW_IPB;
     const int item = blockIdx.x * DW_IPB + il;                 // (tap, c8)
-    const bool live = item < T * c8n;
+    const bool live = item < NT * c8n;
     const int tap = live ? item / c8n : 0, c8 = live ? item - tap * c8n : 0;
     const int a = tap / k, b = tap - a * k;
     const int nrows = N * P;
@@ -498,7 +518,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(
     if (live) {
         for (int r = r0; r < r1; ++r) {
             const int n = r / P, p = r - n * P;
-            const unsigned short* dyr = dy + (long long)r * Q * C + c8 * 8;
+            const T* dyr = dy + (long long)r * Q * C + c8 * 8;
             if (do_cs) {
                 for (int q = pl; q < Q; q += DW_PL) {
                     float g[8];
@@ -509,7 +529,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(
             }
             const int h = p * stride - pad_t + a;
             if ((unsigned)h >= (unsigned)H) continue;
-            const unsigned short* xr = x + ((long long)n * H + h) * W * C + c8 * 8 + (long long)(b - pad_l) * C;
+            const T* xr = x + ((long long)n * H + h) * W * C + c8 * 8 + (long long)(b - pad_l) * C;
             int q = qlo + pl;
             for (; q + DW_PL < qhi; q += 2 * DW_PL) {
                 float g0[8], v0[8], g1[8], v1[8];
@@ -519,14 +539,14 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(
                 load8(xr + (long long)(q + DW_PL) * stride * C, v1);
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    acc[e] += (SWISH ? swishf(v0[e]) : v0[e]) * g0[e] + (SWISH ? swishf(v1[e]) : v1[e]) * g1[e];
+                    acc[e] += (SWISH ? Act<T>::sw(v0[e]) : v0[e]) * g0[e] + (SWISH ? Act<T>::sw(v1[e]) : v1[e]) * g1[e];
             }
             for (; q < qhi; q += DW_PL) {
                 float g[8], v[8];
                 load8(dyr + (long long)q * C, g);
                 load8(xr + (long long)q * stride * C, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += (SWISH ? swishf(v[e]) : v[e]) * g[e];
+                for (int e = 0; e < 8; ++e) acc[e] += (SWISH ? Act<T>::sw(v[e]) : v[e]) * g[e];
             }
         }
     }
@@ -734,11 +754,11 @@ extern "C" int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, f
     const int by = (nrows + rows - 1) / rows;
     dim3 grid((unsigned)bx, (unsigned)by);
     if (in_swish)
-        hipLaunchKernelGGL(dwconv_wgrad_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((dwconv_wgrad_kernel<unsigned short, true>), grid, dim3(256), 0, (hipStream_t)stream,
                            (const unsigned short*)x, (const unsigned short*)dy, dw_t, colsum, N, H, W, C, k, stride,
                            pad_t, pad_l, P, Q, rows);
     else
-        hipLaunchKernelGGL(dwconv_wgrad_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((dwconv_wgrad_kernel<unsigned short, false>), grid, dim3(256), 0, (hipStream_t)stream,
                            (const unsigned short*)x, (const unsigned short*)dy, dw_t, colsum, N, H, W, C, k, stride,
                            pad_t, pad_l, P, Q, rows);
     return check_launch("dwconv_wgrad_kernel");
@@ -826,9 +846,9 @@ extern "C" int mi355_dw_param_grads(const float* G_t, const float* w, const floa
 // ============================================================================ squeeze-excite
 // partial[n][slab][c] = scale * sum over a slab of pixels (summed in a fixed order by the consumer:
 // bit-reproducible, no atomics, nothing to zero); grid (slabs, N)
-template <bool SWISH, bool MUL>
-__global__ __launch_bounds__(256) void se_reduce_kernel(const unsigned short* __restrict__ a,
-                                                        const unsigned short* __restrict__ z, float* __restrict__ out,
+template <typename T, bool SWISH, bool MUL>
+__global__ __launch_bounds__(256) void se_reduce_kernel(const T* __restrict__ a,
+                                                        const T* __restrict__ z, float* __restrict__ out,
                                                         int HW, int C, int rows_per_block, float scale) {
     __shared__ float s_acc[2048 + 8];
     const int c8n = C >> 3;
@@ -850,10 +870,10 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const unsigned short* __
                     float g[8];
                     load8(a + ((long long)n * HW + m) * C + c8 * 8, g);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += g[e] * (SWISH ? swishf(v[e]) : v[e]);
+                    for (int e = 0; e < 8; ++e) acc[e] += g[e] * (SWISH ? Act<T>::sw(v[e]) : v[e]);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += SWISH ? swishf(v[e]) : v[e];
+                    for (int e = 0; e < 8; ++e) acc[e] += SWISH ? Act<T>::sw(v[e]) : v[e];
                 }
             }
         }
@@ -898,10 +918,10 @@ extern "C" int mi355_se_pool(const void* z, int in_swish, float* pool, int N, in
     se_grid(N, HW, &rows, &grid);
     const float sc = 1.0f / (float)HW;
     if (in_swish)
-        hipLaunchKernelGGL((se_reduce_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, nullptr,
+        hipLaunchKernelGGL((se_reduce_kernel<unsigned short, true, false>), grid, dim3(256), 0, (hipStream_t)stream, nullptr,
                            (const unsigned short*)z, pool, HW, C, rows, sc);
     else
-        hipLaunchKernelGGL((se_reduce_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, nullptr,
+        hipLaunchKernelGGL((se_reduce_kernel<unsigned short, false, false>), grid, dim3(256), 0, (hipStream_t)stream, nullptr,
                            (const unsigned short*)z, pool, HW, C, rows, sc);
     return check_launch("se_pool");
 }
@@ -910,7 +930,7 @@ extern "C" int mi355_se_bwd_reduce(const void* gu, const void* z, float* ggate, 
     MI355_REQUIRE(gu && z && ggate && N > 0 && N <= 65535 && HW > 0 && C > 0 && C % 8 == 0, "se_bwd_reduce: bad args");
     int rows; dim3 grid;
     se_grid(N, HW, &rows, &grid);
-    hipLaunchKernelGGL((se_reduce_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((se_reduce_kernel<unsigned short, true, true>), grid, dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)gu, (const unsigned short*)z, ggate, HW, C, rows, 1.0f);
     return check_launch("se_bwd_reduce");
 }
@@ -1053,8 +1073,9 @@ extern "C" int mi355_se_fc_bwd(const float* pool, const float* w1, const float* 
     return check_launch("se_fc_bwd_kernel");
 }
 
-__global__ void se_scale_kernel(const unsigned short* __restrict__ z, const float* __restrict__ gate,
-                                unsigned short* __restrict__ u, long long total, int HW, int C) {
+template <typename T>
+__global__ void se_scale_kernel(const T* __restrict__ z, const float* __restrict__ gate,
+                                T* __restrict__ u, long long total, int HW, int C) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int c8n = C >> 3;
@@ -1064,21 +1085,22 @@ __global__ void se_scale_kernel(const unsigned short* __restrict__ z, const floa
     load8(z + t * 8, v);
     const float* g = gate + n * C + c8 * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = swishf(v[e]) * g[e];
+    for (int e = 0; e < 8; ++e) v[e] = Act<T>::sw(v[e]) * g[e];
     store8(u + t * 8, v);
 }
 
 extern "C" int mi355_se_scale(const void* z, const float* gate, void* u, int N, int HW, int C, void* stream) {
     MI355_REQUIRE(z && gate && u && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_scale: bad args");
     const long long total = (long long)N * HW * (C / 8);
-    hipLaunchKernelGGL(se_scale_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(se_scale_kernel<unsigned short>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)z, gate, (unsigned short*)u, total, HW, C);
     return check_launch("se_scale_kernel");
 }
 
-__global__ void se_bwd_apply_kernel(const unsigned short* __restrict__ gu, const unsigned short* __restrict__ z,
+template <typename T>
+__global__ void se_bwd_apply_kernel(const T* __restrict__ gu, const T* __restrict__ z,
                                     const float* __restrict__ gate, const float* __restrict__ gpool,
-                                    unsigned short* __restrict__ gz, long long total, int HW, int C) {
+                                    T* __restrict__ gz, long long total, int HW, int C) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int c8n = C >> 3;
@@ -1091,7 +1113,7 @@ __global__ void se_bwd_apply_kernel(const unsigned short* __restrict__ gu, const
     const float* gp = gpool + n * C + c8 * 8;
     const float inv = 1.0f / (float)HW;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = (g[e] * ga[e] + gp[e] * inv) * dswishf(v[e]);
+    for (int e = 0; e < 8; ++e) g[e] = (g[e] * ga[e] + gp[e] * inv) * Act<T>::dsw(v[e]);
     store8(gz + t * 8, g);
 }
 
@@ -1099,7 +1121,7 @@ extern "C" int mi355_se_bwd_apply(const void* gu, const void* z, const float* ga
                                   int N, int HW, int C, void* stream) {
     MI355_REQUIRE(gu && z && gate && gpool && gz && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_bwd_apply: bad args");
     const long long total = (long long)N * HW * (C / 8);
-    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(se_bwd_apply_kernel<unsigned short>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)gu, (const unsigned short*)z, gate, gpool, (unsigned short*)gz, total, HW, C);
     return check_launch("se_bwd_apply_kernel");
 }
@@ -1158,12 +1180,12 @@ extern "C" int mi355_fusion_weights_bwd(const float* p, int n, float eps, const 
     return check_launch("fusion_weights_bwd_kernel");
 }
 
-template <bool WGRAD>
-__global__ __launch_bounds__(256) void bifpn_node_kernel(const unsigned short* __restrict__ gz,
-                                                         const unsigned short* __restrict__ in0,
-                                                         const unsigned short* __restrict__ in1, int up1,
-                                                         const unsigned short* __restrict__ in2,
-                                                         const float* __restrict__ w, unsigned short* __restrict__ z,
+template <typename T, bool WGRAD>
+__global__ __launch_bounds__(256) void bifpn_node_kernel(const T* __restrict__ gz,
+                                                         const T* __restrict__ in0,
+                                                         const T* __restrict__ in1, int up1,
+                                                         const T* __restrict__ in2,
+                                                         const float* __restrict__ w, T* __restrict__ z,
                                                          float* __restrict__ gw, int N, int H, int W, int C) {
     const int c8n = C >> 3;
     const long long total = (long long)N * H * W * c8n;
@@ -1210,7 +1232,7 @@ extern "C" int mi355_bifpn_node_fwd(const void* in0, const void* in1, int up1, c
     MI355_REQUIRE(in0 && in1 && w && z && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bifpn_node_fwd: bad args");
     MI355_REQUIRE(!up1 || (H % 2 == 0 && W % 2 == 0), "bifpn_node_fwd: upsample needs even H, W");
     const long long total = (long long)N * H * W * (C / 8);
-    hipLaunchKernelGGL(bifpn_node_kernel<false>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, nullptr,
+    hipLaunchKernelGGL((bifpn_node_kernel<unsigned short, false>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, nullptr,
                        (const unsigned short*)in0, (const unsigned short*)in1, up1, (const unsigned short*)in2, w,
                        (unsigned short*)z, nullptr, N, H, W, C);
     return check_launch("bifpn_node_kernel<fwd>");
@@ -1220,14 +1242,15 @@ extern "C" int mi355_bifpn_node_wgrad(const void* gz, const void* in0, const voi
                                       float* gw, int N, int H, int W, int C, void* stream) {
     MI355_REQUIRE(gz && in0 && in1 && gw && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bifpn_node_wgrad: bad args");
     const long long total = (long long)N * H * W * (C / 8);
-    hipLaunchKernelGGL(bifpn_node_kernel<true>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((bifpn_node_kernel<unsigned short, true>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)gz, (const unsigned short*)in0, (const unsigned short*)in1, up1,
                        (const unsigned short*)in2, nullptr, nullptr, gw, N, H, W, C);
     return check_launch("bifpn_node_kernel<wgrad>");
 }
 
-__global__ void axpy_kernel(const unsigned short* __restrict__ src, const float* __restrict__ w, int wi,
-                            unsigned short* __restrict__ dst, long long n8, int accumulate) {
+template <typename T>
+__global__ void axpy_kernel(const T* __restrict__ src, const float* __restrict__ w, int wi,
+                            T* __restrict__ dst, long long n8, int accumulate) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n8) return;
     const float a = w ? w[wi] : 1.0f;
@@ -1242,14 +1265,15 @@ __global__ void axpy_kernel(const unsigned short* __restrict__ src, const float*
 extern "C" int mi355_axpy_bf16(const void* src, const float* w, int wi, void* dst, int64_t n, int accumulate,
                                void* stream) {
     MI355_REQUIRE(src && dst && n > 0 && n % 8 == 0, "axpy: n must be a multiple of 8");
-    hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(axpy_kernel<unsigned short>, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)src, w, wi, (unsigned short*)dst, (long long)(n / 8), accumulate);
     return check_launch("axpy_kernel");
 }
 
 // drop-connect (utils_efficientnet.py:85-94): dst = src / keep * floor(keep + u[n]) (+ addend), one uniform per image
-__global__ void drop_connect_kernel(const unsigned short* __restrict__ src, const float* __restrict__ u, float keep,
-                                    const unsigned short* __restrict__ addend, unsigned short* __restrict__ dst,
+template <typename T>
+__global__ void drop_connect_kernel(const T* __restrict__ src, const float* __restrict__ u, float keep,
+                                    const T* __restrict__ addend, T* __restrict__ dst,
                                     long long per_image8) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= per_image8) return;
@@ -1274,14 +1298,15 @@ extern "C" int mi355_drop_connect(const void* src, const float* u, float keep, c
     MI355_REQUIRE(src && u && dst && N > 0 && N <= 65535 && per_image > 0 && per_image % 8 == 0,
                   "drop_connect: bad args (per_image must be a multiple of 8)");
     MI355_REQUIRE(keep > 0.0f && keep <= 1.0f, "drop_connect: keep probability %g outside (0, 1]", (double)keep);
-    hipLaunchKernelGGL(drop_connect_kernel, dim3(blocks_for(per_image / 8), (unsigned)N), dim3(256), 0,
+    hipLaunchKernelGGL(drop_connect_kernel<unsigned short>, dim3(blocks_for(per_image / 8), (unsigned)N), dim3(256), 0,
                        (hipStream_t)stream, (const unsigned short*)src, u, keep, (const unsigned short*)addend,
                        (unsigned short*)dst, (long long)(per_image / 8));
     return check_launch("drop_connect_kernel");
 }
 
-__global__ void upsample_bwd_axpy_kernel(const unsigned short* __restrict__ src, const float* __restrict__ w, int wi,
-                                         unsigned short* __restrict__ dst, int N, int H, int W, int C, int accumulate) {
+template <typename T>
+__global__ void upsample_bwd_axpy_kernel(const T* __restrict__ src, const float* __restrict__ w, int wi,
+                                         T* __restrict__ dst, int N, int H, int W, int C, int accumulate) {
     const int c8n = C >> 3, P = H >> 1, Q = W >> 1;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N * P * Q * c8n) return;
@@ -1312,7 +1337,7 @@ extern "C" int mi355_upsample_bwd_axpy(const void* src, const float* w, int wi, 
     MI355_REQUIRE(src && dst && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0,
                   "upsample_bwd_axpy: bad args");
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 8);
-    hipLaunchKernelGGL(upsample_bwd_axpy_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(upsample_bwd_axpy_kernel<unsigned short>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)src, w, wi, (unsigned short*)dst, N, H, W, C, accumulate);
     return check_launch("upsample_bwd_axpy_kernel");
 }
@@ -1324,7 +1349,8 @@ static void same_pad(int n, int k, int s, int* before, int* out) {
     *before = extra / 2;
 }
 
-__global__ void maxpool_same_fwd_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
+template <typename T>
+__global__ void maxpool_same_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
                                         signed char* __restrict__ idx, int N, int H, int W, int C, int P, int Q,
                                         int pad_t, int pad_l) {
     const int c8n = C >> 3;
@@ -1365,13 +1391,14 @@ extern "C" int mi355_maxpool_same_fwd(const void* in, void* out, int8_t* idx, in
     same_pad(H, 3, 2, &pt, &P);
     same_pad(W, 3, 2, &pl, &Q);
     const long long total = (long long)N * P * Q * (C / 8);
-    hipLaunchKernelGGL(maxpool_same_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(maxpool_same_fwd_kernel<unsigned short>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)in, (unsigned short*)out, (signed char*)idx, N, H, W, C, P, Q, pt, pl);
     return check_launch("maxpool_same_fwd_kernel");
 }
 
-__global__ void maxpool_same_bwd_kernel(const unsigned short* __restrict__ gout, const signed char* __restrict__ idx,
-                                        unsigned short* __restrict__ gin, int N, int H, int W, int C, int P, int Q,
+template <typename T>
+__global__ void maxpool_same_bwd_kernel(const T* __restrict__ gout, const signed char* __restrict__ idx,
+                                        T* __restrict__ gin, int N, int H, int W, int C, int P, int Q,
                                         int pad_t, int pad_l, int accumulate) {
     const int c8n = C >> 3;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1412,8 +1439,172 @@ extern "C" int mi355_maxpool_same_bwd(const void* gout, const int8_t* idx, void*
     same_pad(H, 3, 2, &pt, &P);
     same_pad(W, 3, 2, &pl, &Q);
     const long long total = (long long)N * H * W * (C / 8);
-    hipLaunchKernelGGL(maxpool_same_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(maxpool_same_bwd_kernel<unsigned short>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)gout, (const signed char*)idx, (unsigned short*)gin, N, H, W, C, P, Q, pt,
                        pl, accumulate);
     return check_launch("maxpool_same_bwd_kernel");
+}
+
+
+// ============================================================================ fp32-accurate mode twins
+// Same arguments as the bf16 entry points above with every activation / gradient tensor fp32 (C a multiple of 8); the
+// generic kernels instantiated over float (exact swish).  A precision mode: none of the tiled / windowed fast paths.
+extern "C" int mi355_dwconv_fwd_f32(const void* in, int in_swish, const float* w_t, const float* bias, void* out, int N,
+                                    int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
+                                    void* stream) {
+    MI355_REQUIRE(in && w_t && out && N > 0 && C > 0 && C % 8 == 0 && k > 0 && stride > 0, "dwconv_fwd_f32: bad args");
+    const long long total = (long long)N * P * Q * (C / 8);
+    if (in_swish)
+        hipLaunchKernelGGL((dwconv_fwd_kernel<float, true>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)in, w_t, bias, (float*)out, N, H, W, C, k, stride, pad_t, pad_l, P, Q);
+    else
+        hipLaunchKernelGGL((dwconv_fwd_kernel<float, false>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)in, w_t, bias, (float*)out, N, H, W, C, k, stride, pad_t, pad_l, P, Q);
+    return check_launch("dwconv_fwd_kernel<float>");
+}
+
+extern "C" int mi355_dwconv_dgrad_f32(const void* dy, const float* w_t, void* dx, const void* zin, int N, int H, int W,
+                                      int C, int k, int stride, int pad_t, int pad_l, int P, int Q, int accumulate,
+                                      void* stream) {
+    MI355_REQUIRE(dy && w_t && dx && N > 0 && C > 0 && C % 8 == 0 && k > 0 && stride > 0, "dwconv_dgrad_f32: bad args");
+    const long long total = (long long)N * H * W * (C / 8);
+    hipLaunchKernelGGL(dwconv_dgrad_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)dy, w_t, (float*)dx, (const float*)zin, N, H, W, C, k, stride, pad_t, pad_l, P, Q,
+                       accumulate);
+    return check_launch("dwconv_dgrad_kernel<float>");
+}
+
+extern "C" int mi355_dwconv_wgrad_f32(const void* x, int in_swish, const void* dy, float* dw_t, float* colsum, int N,
+                                      int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
+                                      void* stream) {
+    MI355_REQUIRE(x && dy && dw_t && N > 0 && C > 0 && C % 8 == 0 && k > 0, "dwconv_wgrad_f32: bad args");
+    const int nrows = N * P;
+    const int items = k * k * (C / 8);
+    const int bx = (items + DW_IPB - 1) / DW_IPB;
+    int chunks = 2048 / bx;
+    if (chunks > 128) chunks = 128;
+    if (chunks < 1) chunks = 1;
+    int rows = (nrows + chunks - 1) / chunks;
+    if (rows < 1) rows = 1;
+    const int by = (nrows + rows - 1) / rows;
+    dim3 grid((unsigned)bx, (unsigned)by);
+    if (in_swish)
+        hipLaunchKernelGGL((dwconv_wgrad_kernel<float, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                           (const float*)dy, dw_t, colsum, N, H, W, C, k, stride, pad_t, pad_l, P, Q, rows);
+    else
+        hipLaunchKernelGGL((dwconv_wgrad_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                           (const float*)dy, dw_t, colsum, N, H, W, C, k, stride, pad_t, pad_l, P, Q, rows);
+    return check_launch("dwconv_wgrad_kernel<float>");
+}
+
+extern "C" int mi355_se_pool_f32(const void* z, int in_swish, float* pool, int N, int HW, int C, void* stream) {
+    MI355_REQUIRE(z && pool && N > 0 && N <= 65535 && HW > 0 && C > 0 && C % 8 == 0, "se_pool_f32: bad args");
+    int rows; dim3 grid;
+    se_grid(N, HW, &rows, &grid);
+    const float sc = 1.0f / (float)HW;
+    if (in_swish)
+        hipLaunchKernelGGL((se_reduce_kernel<float, true, false>), grid, dim3(256), 0, (hipStream_t)stream, nullptr,
+                           (const float*)z, pool, HW, C, rows, sc);
+    else
+        hipLaunchKernelGGL((se_reduce_kernel<float, false, false>), grid, dim3(256), 0, (hipStream_t)stream, nullptr,
+                           (const float*)z, pool, HW, C, rows, sc);
+    return check_launch("se_pool_f32");
+}
+
+extern "C" int mi355_se_bwd_reduce_f32(const void* gu, const void* z, float* ggate, int N, int HW, int C, void* stream) {
+    MI355_REQUIRE(gu && z && ggate && N > 0 && N <= 65535 && HW > 0 && C > 0 && C % 8 == 0, "se_bwd_reduce_f32: bad args");
+    int rows; dim3 grid;
+    se_grid(N, HW, &rows, &grid);
+    hipLaunchKernelGGL((se_reduce_kernel<float, true, true>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)gu,
+                       (const float*)z, ggate, HW, C, rows, 1.0f);
+    return check_launch("se_bwd_reduce_f32");
+}
+
+extern "C" int mi355_se_scale_f32(const void* z, const float* gate, void* u, int N, int HW, int C, void* stream) {
+    MI355_REQUIRE(z && gate && u && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_scale_f32: bad args");
+    const long long total = (long long)N * HW * (C / 8);
+    hipLaunchKernelGGL(se_scale_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)z,
+                       gate, (float*)u, total, HW, C);
+    return check_launch("se_scale_kernel<float>");
+}
+
+extern "C" int mi355_se_bwd_apply_f32(const void* gu, const void* z, const float* gate, const float* gpool, void* gz,
+                                      int N, int HW, int C, void* stream) {
+    MI355_REQUIRE(gu && z && gate && gpool && gz && N > 0 && HW > 0 && C > 0 && C % 8 == 0, "se_bwd_apply_f32: bad args");
+    const long long total = (long long)N * HW * (C / 8);
+    hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)gu, (const float*)z, gate, gpool, (float*)gz, total, HW, C);
+    return check_launch("se_bwd_apply_kernel<float>");
+}
+
+extern "C" int mi355_bifpn_node_fwd_f32(const void* in0, const void* in1, int up1, const void* in2, const float* w,
+                                        void* z, int N, int H, int W, int C, void* stream) {
+    MI355_REQUIRE(in0 && in1 && w && z && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bifpn_node_fwd_f32: bad args");
+    MI355_REQUIRE(!up1 || (H % 2 == 0 && W % 2 == 0), "bifpn_node_fwd_f32: upsample needs even H, W");
+    const long long total = (long long)N * H * W * (C / 8);
+    hipLaunchKernelGGL((bifpn_node_kernel<float, false>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       nullptr, (const float*)in0, (const float*)in1, up1, (const float*)in2, w, (float*)z, nullptr, N, H,
+                       W, C);
+    return check_launch("bifpn_node_kernel<float, fwd>");
+}
+
+extern "C" int mi355_bifpn_node_wgrad_f32(const void* gz, const void* in0, const void* in1, int up1, const void* in2,
+                                          float* gw, int N, int H, int W, int C, void* stream) {
+    MI355_REQUIRE(gz && in0 && in1 && gw && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bifpn_node_wgrad_f32: bad args");
+    const long long total = (long long)N * H * W * (C / 8);
+    hipLaunchKernelGGL((bifpn_node_kernel<float, true>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)gz, (const float*)in0, (const float*)in1, up1, (const float*)in2, nullptr, nullptr,
+                       gw, N, H, W, C);
+    return check_launch("bifpn_node_kernel<float, wgrad>");
+}
+
+extern "C" int mi355_axpy_f32(const void* src, const float* w, int wi, void* dst, int64_t n, int accumulate, void* stream) {
+    MI355_REQUIRE(src && dst && n > 0 && n % 8 == 0, "axpy_f32: n must be a multiple of 8");
+    hipLaunchKernelGGL(axpy_kernel<float>, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const float*)src,
+                       w, wi, (float*)dst, (long long)(n / 8), accumulate);
+    return check_launch("axpy_kernel<float>");
+}
+
+extern "C" int mi355_drop_connect_f32(const void* src, const float* u, float keep, const void* addend, void* dst, int N,
+                                      int64_t per_image, void* stream) {
+    MI355_REQUIRE(src && u && dst && N > 0 && N <= 65535 && per_image > 0 && per_image % 8 == 0,
+                  "drop_connect_f32: bad args (per_image must be a multiple of 8)");
+    MI355_REQUIRE(keep > 0.0f && keep <= 1.0f, "drop_connect_f32: keep probability %g outside (0, 1]", (double)keep);
+    hipLaunchKernelGGL(drop_connect_kernel<float>, dim3(blocks_for(per_image / 8), (unsigned)N), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)src, u, keep, (const float*)addend, (float*)dst,
+                       (long long)(per_image / 8));
+    return check_launch("drop_connect_kernel<float>");
+}
+
+extern "C" int mi355_upsample_bwd_axpy_f32(const void* src, const float* w, int wi, void* dst, int N, int H, int W, int C,
+                                           int accumulate, void* stream) {
+    MI355_REQUIRE(src && dst && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0,
+                  "upsample_bwd_axpy_f32: bad args");
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(upsample_bwd_axpy_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)src, w, wi, (float*)dst, N, H, W, C, accumulate);
+    return check_launch("upsample_bwd_axpy_kernel<float>");
+}
+
+extern "C" int mi355_maxpool_same_fwd_f32(const void* in, void* out, int8_t* idx, int N, int H, int W, int C, void* stream) {
+    MI355_REQUIRE(in && out && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_same_fwd_f32: bad args");
+    int pt, pl, P, Q;
+    same_pad(H, 3, 2, &pt, &P);
+    same_pad(W, 3, 2, &pl, &Q);
+    const long long total = (long long)N * P * Q * (C / 8);
+    hipLaunchKernelGGL(maxpool_same_fwd_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)in, (float*)out, (signed char*)idx, N, H, W, C, P, Q, pt, pl);
+    return check_launch("maxpool_same_fwd_kernel<float>");
+}
+
+extern "C" int mi355_maxpool_same_bwd_f32(const void* gout, const int8_t* idx, void* gin, int N, int H, int W, int C,
+                                          int accumulate, void* stream) {
+    MI355_REQUIRE(gout && idx && gin && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_same_bwd_f32: bad args");
+    int pt, pl, P, Q;
+    same_pad(H, 3, 2, &pt, &P);
+    same_pad(W, 3, 2, &pl, &Q);
+    const long long total = (long long)N * H * W * (C / 8);
+    hipLaunchKernelGGL(maxpool_same_bwd_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)gout, (const signed char*)idx, (float*)gin, N, H, W, C, P, Q, pt, pl, accumulate);
+    return check_launch("maxpool_same_bwd_kernel<float>");
 }

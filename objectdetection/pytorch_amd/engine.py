@@ -80,7 +80,18 @@ def precision_of(model):
 # entry points that have an fp32-mode twin taking the same arguments (include/mi355det_conv.h)
 F32_TWINS = {'mi355_conv_gather': 'mi355_conv_gather_f32', 'mi355_conv_wgrad_slabs': 'mi355_conv_wgrad_slabs_f32',
              'mi355_maxpool3x3s2_fwd': 'mi355_maxpool3x3s2_fwd_f32', 'mi355_maxpool3x3s2_bwd': 'mi355_maxpool3x3s2_bwd_f32',
-             'mi355_sumpool2x2_bf16': 'mi355_sumpool2x2_f32', 'mi355_relu_mask_bf16': 'mi355_relu_mask_f32'}
+             'mi355_sumpool2x2_bf16': 'mi355_sumpool2x2_f32', 'mi355_relu_mask_bf16': 'mi355_relu_mask_f32',
+             # EfficientDet (include/mi355det_effdet.h)
+             'mi355_dwconv_fwd': 'mi355_dwconv_fwd_f32', 'mi355_dwconv_dgrad': 'mi355_dwconv_dgrad_f32',
+             'mi355_dwconv_wgrad': 'mi355_dwconv_wgrad_f32', 'mi355_se_pool': 'mi355_se_pool_f32',
+             'mi355_se_scale': 'mi355_se_scale_f32', 'mi355_se_bwd_reduce': 'mi355_se_bwd_reduce_f32',
+             'mi355_se_bwd_apply': 'mi355_se_bwd_apply_f32', 'mi355_bifpn_node_fwd': 'mi355_bifpn_node_fwd_f32',
+             'mi355_bifpn_node_wgrad': 'mi355_bifpn_node_wgrad_f32', 'mi355_axpy_bf16': 'mi355_axpy_f32',
+             'mi355_drop_connect': 'mi355_drop_connect_f32', 'mi355_upsample_bwd_axpy': 'mi355_upsample_bwd_axpy_f32',
+             'mi355_maxpool_same_fwd': 'mi355_maxpool_same_fwd_f32', 'mi355_maxpool_same_bwd': 'mi355_maxpool_same_bwd_f32'}
+# entry points that never see an activation tensor (fp32 vectors / parameter tables): the same in both modes
+F32_NEUTRAL = ('mi355_se_fc', 'mi355_se_fc_bwd', 'mi355_se_slabs', 'mi355_fusion_weights', 'mi355_dw_prep', 'mi355_dw_param',
+               'mi355_prep_weights', 'mi355_param_grads', 'mi355_bn_nhwc', 'mi355_focal', 'mi355_stream')
 
 
 class RetinaPlan(object):
@@ -91,7 +102,7 @@ class RetinaPlan(object):
         self.lib = _lib.lib()
         self.prec = precision_of(model)
         if self.prec == 'fp32' and not self.supports_fp32:
-            raise _lib.Mi355Error('%s: the fp32-accurate mode is built for the RetinaNet plans only' % type(self).__name__)
+            raise _lib.Mi355Error('%s: the fp32-accurate mode is not built for this plan' % type(self).__name__)
         self.adt = torch.float32 if self.prec == 'fp32' else torch.bfloat16     # activation / gradient storage
         self.esz = 4 if self.prec == 'fp32' else 2
         self.keep = []                 # ctypes objects referenced by the steps
@@ -161,7 +172,7 @@ class RetinaPlan(object):
     def _step(self, lst, name, *args):
         self.keep.append(args)
         if self.prec == 'fp32':
-            if name not in F32_TWINS and name.startswith(('mi355_conv_', 'mi355_maxpool', 'mi355_sumpool', 'mi355_relu')):
+            if name not in F32_TWINS and not name.startswith(F32_NEUTRAL):
                 raise _lib.Mi355Error('%s has no fp32-mode twin' % name)
             name = F32_TWINS.get(name, name)
         lst.append((getattr(self.lib, name), args, name))

@@ -67,7 +67,6 @@ class SeSpec(object):
 
 
 class EffDetPlan(RetinaPlan):
-    supports_fp32 = False          # (depthwise / SE / BiFPN kernels store bf16)
     # ------------------------------------------------------------------ meta / layers
     def _meta(self):
         self.num_classes = self.model.num_classes
@@ -515,7 +514,7 @@ class EffDetPlan(RetinaPlan):
             self.fwd_launches.append((spec, [(B, h, w)]))
 
             def bwd(t=t, spec=spec, h=h, w=w, off=off):
-                dy_ptr = gout.data_ptr() + 2 * off * pitch
+                dy_ptr = gout.data_ptr() + self.esz * off * pitch
                 wp = fwd_problem(t, dy_ptr, 1, 1, 1, 0, K=pitch)
                 wp.out_sN = self.ncells * pitch
                 self._wgrad([wp], spec, B * h * w)
@@ -545,7 +544,7 @@ class EffDetPlan(RetinaPlan):
             return
         super(EffDetPlan, self)._step(lst, name, *args)
 
-    SIDE_STEPS = RetinaPlan.SIDE_STEPS + ('mi355_dwconv_wgrad',)
+    SIDE_STEPS = RetinaPlan.SIDE_STEPS + ('mi355_dwconv_wgrad', 'mi355_dwconv_wgrad_f32')
 
     def _run(self, steps, stream):
         """As RetinaPlan._run (weight gradients on the side stream: they only read activations / output

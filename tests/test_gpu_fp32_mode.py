@@ -156,3 +156,76 @@ def test_fp32_trainer_step_matches_torch_adamw(golden_dir, dev):
     np.testing.assert_allclose(losses[1].item(), g['reg_loss'].item(), rtol=LOSS_RTOL)
     l2 = tr.step(img, ann)
     assert torch.isfinite(l2).all() and tr.step_count == 2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# EfficientDet in the fp32-accurate mode: depthwise / SE / BiFPN kernels instantiated over fp32 storage with the exact
+# swish, the 1x1 convs on the f32 matrix instruction.  Against the reference's goldens (the reference computes in fp32).
+def _effdet(golden_dir, tag, dev, drop_connect=False):
+    from objectdetection.pytorch_amd.architectures import efficientdet
+    g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
+    coef, (H, W), B, nc = int(g['coef']), g['hw'], int(g['batch']), int(g['num_classes'])
+    model = efficientdet.build_efficientdet('efficientdet-d%d' % coef, num_classes=nc)
+    model.precision = 'fp32'
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=float(g['gain']), head_std=float(g['head_std']))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    model.train()
+    model.freeze_bn()
+    if not drop_connect:
+        synth.disable_drop_connect(model)
+    img = torch.from_numpy(synth.synth_images(B, int(H), int(W), seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(B, int(H), int(W), 6, 8, nc, seed=2)).to(dev)
+    return g, model, img, ann
+
+
+def _effdet_check(g, model, img, ann, dev):
+    if 'head_idx' in g.files:
+        cls, reg = model(img, return_head=True)
+        idx = g['head_idx']
+        assert _rel(reg.cpu().numpy()[:, idx], g['reg_rows']) < HEAD_TOL
+        assert _rel(cls.cpu().numpy()[:, idx], g['cls_rows']) < HEAD_TOL
+    cl, rl = model(img, ann)
+    np.testing.assert_allclose(cl.item(), g['cls_loss'].item(), rtol=LOSS_RTOL)
+    np.testing.assert_allclose(rl.item(), g['reg_loss'].item(), rtol=LOSS_RTOL)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = dict((k, p.grad) for k, p in model.named_parameters())
+    gn = np.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values() if v is not None))
+    np.testing.assert_allclose(gn, float(g['grad_global_norm']), rtol=2e-4)
+    worst = ('', 0.0)
+    for key in g.files:
+        if key.startswith('grad/') and key.endswith('/val'):
+            name = key[5:-4]
+            if grads[name] is None:                            # D6: unused fusion weights (reference: grad None)
+                assert np.linalg.norm(g[key]) == 0.0
+                continue
+            sel = torch.from_numpy(g['grad/%s/idx' % name]).to(dev)
+            got = grads[name].reshape(-1)[sel].cpu().numpy().astype(np.float64)
+            ref = g[key].astype(np.float64)
+            if np.linalg.norm(ref) < 1e-6 * gn:                # zero / cancelling gradients: absolute check
+                assert np.abs(got - ref).max() <= 1e-6 * gn, (name, got, ref)
+                continue
+            rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            if rel > worst[1]:
+                worst = (name, rel)
+            # (no fp64 run in these goldens: the 1e-3 bound of the verdict, 3e-3 for the SE / stem tensors whose sums
+            #  cancel like RetinaNet's conv1.weight)
+            assert rel <= 3e-3, (name, rel)
+    print('fp32 EfficientDet: cls %.7g (ref %.7g) reg %.7g (ref %.7g) worst sampled-grad relL2 %s %.3g'
+          % (cl.item(), g['cls_loss'].item(), rl.item(), g['reg_loss'].item(), worst[0], worst[1]))
+
+
+@pytest.mark.parametrize('tag', ['effdet_d0_128', 'effdet_d2_128x256', 'effdet_d6_128'])
+def test_fp32_mode_efficientdet_vs_reference_golden(golden_dir, dev, tag):
+    g, model, img, ann = _effdet(golden_dir, tag, dev)
+    _effdet_check(g, model, img, ann, dev)
+
+
+def test_fp32_mode_efficientdet_drop_connect_golden(golden_dir, dev):
+    g, model, img, ann = _effdet(golden_dir, 'effdet_d0_dropconnect_128', dev, drop_connect=True)
+    plan = model._plan(img)
+    assert plan.drop_connect and plan.prec == 'fp32'
+    plan.dc_inject = torch.from_numpy(g['dc_u']).to(dev)      # the uniforms the reference drew when the golden was made
+    _effdet_check(g, model, img, ann, dev)
