@@ -423,6 +423,156 @@ __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(
 
 
 // ---------------------------------------------------------------------------------------------
+// RING: the narrow tile (128 x 64, four wave rows of 32 x 64) with a THREE-stage LDS-DMA ring for the launches that
+// cannot fill the chip with blocks (256-767 tiles: the 16^2 / 32^2 / 64^2 convs of ResNet layers 2-4 and the pyramid):
+// with one or two blocks per CU nothing but the block's own pipeline hides the DMA latency, and the two-stage form
+// exposes most of it every k-step (layer3 3x3: 0.8 us per k-step for 0.12 us of MFMA work).  Here the DMA of k-step
+// t + 2 is issued while k-step t is on the matrix cores: one raw s_barrier per k-step, a counted s_waitcnt vmcnt that
+// leaves the newest stage in flight, fragment reads as opaque asm (hipcc would otherwise order every visible LDS read
+// behind ALL pending LDS-DMA with vmcnt(0): guide, "Pipelining across barriers").
+//   iteration t:  vmcnt(pieces of stage t+1) -> s_barrier -> issue(t+2 -> buf (t+2)%3) -> read + MFMA buf t%3
+// RAW: every thread waits for its own pieces of stage t, then the barrier, then anyone reads.  WAR: buf (t+2)%3 was read
+// in iteration t-1; those ds_reads were retired (lgkmcnt(0)) before that wave's MFMAs, i.e. before it reached this barrier.
+template <int OFF>
+__device__ __forceinline__ s8v lds_b128(unsigned addr) {
+    s8v v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void conv_gather_ring_kernel(const LaunchDev L) {
+    constexpr int NTHREADS = 256, BM = 128, BNT = 64, TA = 2, RS = 3;
+    constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = A_BYTES + BNT * BK * 2;      // 24 KiB
+    constexpr int NB = BNT * 8 / NTHREADS;                                            // 2
+    constexpr int ROWSTEP = NTHREADS / 8;
+    constexpr int PIECES = 4 + NB;                                                    // DMA instructions per thread and stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ long long s_outoff[BM];
+    __shared__ long long s_addoff[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m_tile = tile / L.n_tiles, n_tile = tile - m_tile * L.n_tiles;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
+        if (i < L.nprob && m_tile >= L.p[i].tile_begin) pi = i;
+    const ProbDev P = L.p[pi];
+    const int m0 = (m_tile - P.tile_begin) * BM;
+    const int n0 = n_tile * BNT;
+    const int PQ = P.P * P.Q;
+
+    if (tid < BM) {
+        const int m = m0 + tid;
+        long long oo = -1, ao = -1;
+        if (m < P.M) {
+            const int n = (int)fdiv((unsigned)m, P.dPQ), rem = m - n * PQ;
+            const int p = (int)fdiv((unsigned)rem, P.dQ), q = rem - p * P.Q;
+            oo = n * P.out_sN + (long long)(p * P.out_mh + P.out_oh) * P.out_sH +
+                 (long long)(q * P.out_mw + P.out_ow) * P.out_sW;
+            ao = n * P.add_sN + (long long)(p >> P.add_shift) * P.add_sH +
+                 (long long)(q >> P.add_shift) * P.add_sW;
+        }
+        s_outoff[tid] = oo;
+        s_addoff[tid] = ao;
+    }
+
+    const int slot = tid & 7;
+    const int kc = slot ^ ((tid >> 3) & 7);
+    int a_base[4], a_ih0[4], a_iw0[4];
+    unsigned b_rowoff[NB];
+    const int wrow = L.T * P.C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + ROWSTEP * i;
+        const int m = m0 + row;
+        const int mc = min(m, P.M - 1);
+        const int n = (int)fdiv((unsigned)mc, P.dPQ), rem = mc - n * PQ;
+        const int p = (int)fdiv((unsigned)rem, P.dQ), q = rem - p * P.Q;
+        a_ih0[i] = m < P.M ? p * P.sh + P.dh0 : -0x40000000;
+        a_iw0[i] = q * P.sw + P.dw0;
+        a_base[i] = n * (int)P.in_sN + ((p * P.sh + P.dh0) * P.W + a_iw0[i]) * P.C;
+        if (i < NB) {
+            const int nn = n0 + row;
+            b_rowoff[i] = nn < L.K ? (unsigned)(nn * wrow) * 2u : OOB_OFFSET;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(P.in, (unsigned)P.in_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(L.w, (unsigned)L.w_bytes);
+    const int ksteps = P.TR * P.TS * (P.C / BK);
+
+    int nx_ti = 0, nx_tj = 0, nx_c = 0;
+    auto issue = [&](int buf) {                          // k-steps are issued strictly in order
+        unsigned char* sa = smem + buf * STAGE_BYTES;
+        unsigned char* sb = sa + A_BYTES;
+        const int ti = nx_ti, tj = nx_tj, c0 = nx_c + kc * 8;
+        nx_c += BK;
+        if (nx_c == P.C) {
+            nx_c = 0;
+            if (++nx_tj == P.TS) { nx_tj = 0; ++nx_ti; }
+        }
+        const int dh = ti * P.dhs, dw = tj * P.dws;
+        const int a_delta = (dh * P.W + dw) * P.C + c0;
+        const unsigned b_delta = (unsigned)(((P.r0 + ti * P.rs) * P.S + (P.s0 + tj * P.ss)) * P.C + c0) * 2u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = (unsigned)(a_ih0[i] + dh) < (unsigned)P.H && (unsigned)(a_iw0[i] + dw) < (unsigned)P.W;
+            const unsigned off = ok ? (unsigned)(a_base[i] + a_delta) * 2u : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (LDS_PTR(void))(sa + (i * NTHREADS + wv * 64) * 16),
+                                                     16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const unsigned off = b_rowoff[i] != OOB_OFFSET ? b_rowoff[i] + b_delta : OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (LDS_PTR(void))(sb + (i * NTHREADS + wv * 64) * 16),
+                                                     16, off, 0, 0, 0);
+        }
+    };
+
+    const int wrow0 = wv * 32;
+    const int fr = lane & 15, fq = lane >> 4;
+    f4v acc[TA][4];
+    const unsigned lds0 = (unsigned)(uintptr_t)(LDS_PTR(void))smem;
+    const unsigned a_rd = lds0 + (wrow0 + fr) * 128;
+    const unsigned b_rd = lds0 + A_BYTES + fr * 128;
+    const unsigned sw0 = ((fq) ^ (fr & 7)) << 4;
+    const unsigned sw1 = ((4 + fq) ^ (fr & 7)) << 4;
+
+    issue(0);
+    init_acc<TA>(acc, L, n0, 0, fq);                    // (bias loads: older than every later DMA in vmcnt order)
+    if (ksteps > 1) issue(1);
+    for (int ks = 0; ks < ksteps; ++ks) {
+        if (ks + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ks + 2 < ksteps) issue((ks + 2) % RS);
+        const unsigned st = (unsigned)((ks % RS) * STAGE_BYTES);
+        s8v af[2][TA], bf[2][4];
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            af[0][t] = t == 0 ? lds_b128<0>(a_rd + st + sw0) : lds_b128<16 * 128>(a_rd + st + sw0);
+            af[1][t] = t == 0 ? lds_b128<0>(a_rd + st + sw1) : lds_b128<16 * 128>(a_rd + st + sw1);
+        }
+        bf[0][0] = lds_b128<0>(b_rd + st + sw0);            bf[1][0] = lds_b128<0>(b_rd + st + sw1);
+        bf[0][1] = lds_b128<16 * 128>(b_rd + st + sw0);     bf[1][1] = lds_b128<16 * 128>(b_rd + st + sw1);
+        bf[0][2] = lds_b128<32 * 128>(b_rd + st + sw0);     bf[1][2] = lds_b128<32 * 128>(b_rd + st + sw1);
+        bf[0][3] = lds_b128<48 * 128>(b_rd + st + sw0);     bf[1][3] = lds_b128<48 * 128>(b_rd + st + sw1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);                  // keep the MFMAs behind the wait (guide 5.4 rule 18)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[sub][j], af[sub][i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                                        // every wave is done with the ring: the epilogue reuses it
+    gather_epilogue<2, TA>(acc, L, P, smem, s_outoff, s_addoff, n0);
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // ROW3: 3x3 / stride 1 / "same" convs with C % 64 == 0 (tower and FPN convs, bottleneck conv2 and
 // their data gradients).  The three taps of one kernel row read the SAME input rows shifted by one
 // pixel, so the activation tile of a (kernel row, 64-channel block) is staged ONCE, two rows longer,
@@ -820,6 +970,17 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     }
     const dim3 g((unsigned)grid), b256(256);
     hipStream_t st = (hipStream_t)stream;
+    // three-stage ring for the narrow-tile launches that are too small for residency to hide the DMA latency
+    static const int ring_mode = [] { const char* e = getenv("MI355_RING"); return e ? atoi(e) : 1; }();
+    if (narrow && !single && !flat && ring_mode && max_ksteps >= 4) {
+        static bool ring_attr = false;
+        if (!ring_attr) {
+            (void)hipFuncSetAttribute((const void*)conv_gather_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * NST);
+            ring_attr = true;
+        }
+        hipLaunchKernelGGL(conv_gather_ring_kernel, g, b256, 3 * NST, st, L);
+        return check_launch("conv_gather_ring_kernel");
+    }
     if (narrow) {
         if (single) {
             if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2, 2>), g, b256, NST, st, L);
