@@ -186,6 +186,12 @@ def plan_launch_bytes(plan):
                     if isinstance(a, ctypes.c_void_p) and v in sizes and v not in seen:
                         seen.add(v)
                         b += sizes[v]
+                    elif isinstance(a, ctypes.Array) and hasattr(a[0], 'aux'):     # Mi355DwLevel table of a multi-map launch
+                        for lv in a:
+                            for v in (lv.x, lv.dy, lv.aux):
+                                if v in sizes and v not in seen:
+                                    seen.add(v)
+                                    b += sizes[v]
             total += b
             per_kernel[name] = per_kernel.get(name, 0.0) + b
     return total, per_kernel
@@ -383,6 +389,7 @@ def main():
     for i in range(args.steps):
         step()
         marks[i + 1].record()
+    host_ms = 1e3 * (time.perf_counter() - t0) / args.steps       # host time to ENQUEUE a step (no sync inside the loop)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -408,6 +415,7 @@ def main():
         'metric': 'images/sec training (%s, %dx%d, bs=%d/GPU)' % (name, S, S, B),
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'ms_per_step_median': round(median_ms, 3),
+        'host_enqueue_ms_per_step': round(host_ms, 3),
         'ranks_seen': ranks_seen, 'ms_per_step_per_rank': per_rank_ms, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': '%s, %dx%d, bf16 MFMA convs (fp32 accumulate, fp32 loss '

@@ -42,6 +42,11 @@ typedef struct Mi355ConvProblem {
     int32_t add_shift;
     int32_t reserved;
     int64_t in_sN;       /* batch stride of `in` in elements; 0 = dense (H*W*C) */
+    const void* weight;  /* optional: THIS problem's weights (same [K][T][C] layout) and bias instead of the launch's:
+                            the pyramid levels of an EfficientDet head conv share the conv but fold a BatchNorm per
+                            level (efficientdet.py:335-353: bn_list[level][i]); NULL = the launch's weight / bias.
+                            bf16 gather launches without split-K only. */
+    const float* bias;   /* used with `weight` (may be NULL) */
 } Mi355ConvProblem;
 
 typedef struct Mi355ConvLaunch {

@@ -35,6 +35,36 @@ int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, const void* z
 int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, float* dw_t, float* colsum, int N,
                        int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
                        void* stream);
+/* The same sums, bit-reproducible (k = 3 / 5, stride 1 / 2, bf16 tensors): the launch stores `nslabs` partial rows
+ * slabs[s][(k*k + 1) * C] = { dw_t partial [k*k][C], colsum partial [C] (written when want_colsum) } with plain
+ * stores, nothing to zero; mi355_dw_param_grads_table adds the rows in index order (Mi355DwGradDesc.nslabs).
+ * mi355_dwconv_wgrad_nslabs returns the row count the launch of that geometry writes.
+ * (reference: the depthwise weight gradient of efficientnet.py:80-115 / utils_extra_efficientnet.py:9-47 as autograd
+ * computes it; a shared head conv gives every pyramid level its own rows of one workspace) */
+int mi355_dwconv_wgrad_nslabs(int N, int C, int k, int stride, int P, int Q, int* nslabs);
+/* ... and for up to MI355_DW_MAX_LEVELS feature maps that share the depthwise weight (the five pyramid levels of an
+ * EfficientDet head conv, efficientdet.py:269-359: `for feat, bn_list in zip(inputs, self.bn_list)` applies the same
+ * conv_list[i] to every level) in ONE launch: the rows hold the sums over all the levels' pixels. */
+#define MI355_DW_MAX_LEVELS 5
+typedef struct Mi355DwLevel {
+    const void* x; const void* dy;              /* bf16 NHWC [N][H][W][C], [N][P][Q][C] */
+    const void* aux;                            /* mi355_dwconv_dgrad_multi: zin (may be NULL); otherwise unused */
+    int32_t H, W, P, Q, pad_t, pad_l;
+} Mi355DwLevel;
+int mi355_dwconv_wgrad_nslabs_multi(const Mi355DwLevel* levels, int nlevels, int N, int C, int k, int stride,
+                                    int* nslabs);
+/* Forward and data gradient of a stride-1 "same" 3x3 / 5x5 depthwise conv over up to MI355_DW_MAX_LEVELS maps in one
+ * launch (same arithmetic as mi355_dwconv_fwd / mi355_dwconv_dgrad per map).  forward: x = input, dy = output;
+ * data gradient: x = dy, dy = dx, aux = zin (dx *= swish'(zin) when non-NULL), accumulate as mi355_dwconv_dgrad. */
+int mi355_dwconv_fwd_multi(const Mi355DwLevel* levels, int nlevels, int in_swish, const float* w_t, const float* bias,
+                           int N, int C, int k, void* stream);
+int mi355_dwconv_dgrad_multi(const Mi355DwLevel* levels, int nlevels, const float* w_t, int N, int C, int k,
+                             int accumulate, void* stream);
+int mi355_dwconv_wgrad_slabs_multi(const Mi355DwLevel* levels, int nlevels, int in_swish, float* slabs,
+                                   int want_colsum, int N, int C, int k, int stride, void* stream);
+int mi355_dwconv_wgrad_slabs(const void* x, int in_swish, const void* dy, float* slabs, int want_colsum, int N,
+                             int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
+                             void* stream);
 /* a = swish(z) elementwise (n elements, multiple of 8): materialised input for dwconv_wgrad */
 int mi355_swish_bf16(const void* z, void* a, int64_t n, void* stream);
 /* finish depthwise parameter grads: dW[c][k][k] (+)= G_t[t][c]*scale[c]; frozen-BN dgamma/dbeta
@@ -67,6 +97,7 @@ typedef struct Mi355DwGradDesc {
     const float* G_t; const float* w; const float* scale; const float* colsum; const float* mean; const float* var;
     float* dW; float* dgamma; float* dbeta;
     float eps; int32_t C; int32_t T; int32_t accumulate;
+    int32_t nslabs; int32_t slab_stride;   /* G_t / colsum: nslabs partial rows, slab_stride floats apart (T <= 25) */
 } Mi355DwGradDesc;
 int mi355_dw_param_grads_table(const Mi355DwGradDesc* table, int n, int max_c, void* stream);
 
@@ -88,6 +119,19 @@ int mi355_se_fc_bwd(const float* pool, const float* w1, const float* w2, const f
                     float* db1, float* dw2, float* db2, int N, int C, int Cse, void* stream);
 int mi355_se_bwd_apply(const void* gu, const void* z, const float* gate, const float* gpool, void* gz,
                        int N, int HW, int C, void* stream);
+/* mi355_se_fc_bwd without atomics, in two parts: the per-sample data path (de [N][C], dr [N][Cse] kept, gpool [N][C]) ... */
+int mi355_se_fc_bwd_data(const float* w1, const float* w2, const float* rpre, const float* gate,
+                         const float* ggate_partial, int slabs, float* de, float* dr, float* gpool, int N, int C,
+                         int Cse, void* stream);
+/* ... and the parameter gradients of every squeeze-excite layer of a plan in one launch (plain stores, sums over the
+ * N samples in index order): dw2[c][j] = sum_n de[n][c] swish(rpre[n][j]), db2 = sum_n de, dw1[j][c] = sum_n dr[n][j]
+ * pool[n][c], db1 = sum_n dr.  max_elems = the largest 2 C Cse + C + Cse in the table. */
+typedef struct Mi355SeGradDesc {
+    const float* pool; const float* rpre; const float* de; const float* dr;
+    float* dw1; float* db1; float* dw2; float* db2;
+    int32_t N, C, Cse, pad_;
+} Mi355SeGradDesc;
+int mi355_se_param_grads_table(const Mi355SeGradDesc* table, int n, int max_elems, void* stream);
 
 /* BiFPN fast-attention node (efficientdet.py:213-265): w = relu(p) / (sum relu(p) + eps) */
 int mi355_fusion_weights_fwd(const float* p, int n, float eps, float* w, void* stream);

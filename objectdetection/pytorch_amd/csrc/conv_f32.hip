@@ -407,6 +407,7 @@ extern "C" int mi355_conv_gather_f32(const Mi355ConvLaunch* launch, void* stream
     int tiles = 0;
     for (int i = 0; i < in.nprob; ++i) {
         const Mi355ConvProblem& s = in.prob[i];
+        MI355_REQUIRE(!s.weight, "conv_gather_f32: per-problem weights are a bf16-launch feature");
         MI355_REQUIRE(s.in && s.out, "conv_gather_f32: problem %d null in/out", i);
         MI355_REQUIRE(s.C == C, "conv_gather_f32: C must be equal across problems");
         MI355_REQUIRE(s.N > 0 && s.H > 0 && s.W > 0 && s.P > 0 && s.Q > 0, "conv_gather_f32: problem %d bad dims", i);

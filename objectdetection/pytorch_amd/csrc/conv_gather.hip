@@ -32,6 +32,8 @@ struct ProbDev {
     void* out;
     const unsigned short* addend;
     const unsigned short* mask;
+    const unsigned short* w;      // this problem's weights / bias (the launch's unless the problem overrides them)
+    const float* bias;
     int N, H, W, C, P, Q, sh, sw;
     int TR, TS, dh0, dhs, dw0, dws;
     int r0, rs, s0, ss, S;
@@ -66,22 +68,22 @@ __device__ __forceinline__ float activate(float v, int act) {
 // (weights are the MFMA A operand), so a lane owns 4 consecutive channels of one pixel and the
 // epilogue stages with 8/16-B LDS writes.  The bias is the accumulator's initial value.
 template <int TA = 4>
-__device__ __forceinline__ void init_acc(f4v (&acc)[TA][4], const LaunchDev& L, int n0, int wn, int fq) {
+__device__ __forceinline__ void init_acc(f4v (&acc)[TA][4], const LaunchDev& L, const float* __restrict__ bias, int n0, int wn, int fq) {
     {
         f4v b4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) b4[j] = (f4v){0.f, 0.f, 0.f, 0.f};
-        if (L.bias) {                                  // uniform branch; 4 loads in flight together
+        if (bias) {                                  // uniform branch; 4 loads in flight together
             if ((L.K & 3) == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    b4[j] = *reinterpret_cast<const f4v*>(L.bias + min(n0 + wn * 64 + j * 16 + fq * 4, L.K - 4));
+                    b4[j] = *reinterpret_cast<const f4v*>(bias + min(n0 + wn * 64 + j * 16 + fq * 4, L.K - 4));
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        b4[j][r] = L.bias[min(n0 + wn * 64 + j * 16 + fq * 4 + r, L.K - 1)];
+                        b4[j][r] = bias[min(n0 + wn * 64 + j * 16 + fq * 4 + r, L.K - 1)];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(
         }
     }
     const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(P.in, (unsigned)P.in_bytes);
-    const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(L.w, (unsigned)L.w_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(P.w, (unsigned)L.w_bytes);
 
     const int ntaps = P.TR * P.TS;
     const int cpt = P.C >> 3;                          // 16-B chunks per tap
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(
     };
     if (ksteps > 0) issue(0, 0);
     // (bias loads are issued behind the first stage's DMA so that both latencies overlap)
-    init_acc<TA>(acc, L, n0, wn, fq);
+    init_acc<TA>(acc, L, P.bias, n0, wn, fq);
     if (STAGES == 2) {
         __syncthreads();
         for (int ks = 0; ks < ksteps; ++ks) {
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_ring_kernel(const LaunchDe
         }
     }
     const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(P.in, (unsigned)P.in_bytes);
-    const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(L.w, (unsigned)L.w_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(P.w, (unsigned)L.w_bytes);
     const int ksteps = P.TR * P.TS * (P.C / BK);
 
     int nx_ti = 0, nx_tj = 0, nx_c = 0;
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_ring_kernel(const LaunchDe
     const unsigned sw1 = ((4 + fq) ^ (fr & 7)) << 4;
 
     issue(0);
-    init_acc<TA>(acc, L, n0, 0, fq);                    // (bias loads: older than every later DMA in vmcnt order)
+    init_acc<TA>(acc, L, P.bias, n0, 0, fq);                    // (bias loads: older than every later DMA in vmcnt order)
     if (ksteps > 1) issue(1);
     for (int ks = 0; ks < ksteps; ++ks) {
         if (ks + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(WM * 128, STAGES == 1 ? 3 : 2) void conv_gather_row
         b_rowoff[i] = nn < L.K ? (unsigned)(nn * wrow) * 2u : OOB_OFFSET;
     }
     const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(P.in, (unsigned)P.in_bytes);
-    const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(L.w, (unsigned)L.w_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(P.w, (unsigned)L.w_bytes);
     const int nchunks = P.C / BK;
     const int ngroups = 3 * nchunks;                   // (kernel row, channel block)
     const int nsteps = 3 * ngroups;                    // x column tap
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(WM * 128, STAGES == 1 ? 3 : 2) void conv_gather_row
         issue_a(0);
         issue_b(0);
     }
-    init_acc(acc, L, n0, wn, fq);
+    init_acc(acc, L, P.bias, n0, wn, fq);
 
     int abuf = 0, step = 0;
     for (int group = 0; group < ngroups; ++group) {
@@ -905,6 +907,10 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         ProbDev& d = L.p[i];
         d.in = (const unsigned short*)s.in;  d.out = s.out;
         d.addend = (const unsigned short*)s.addend;  d.mask = (const unsigned short*)s.mask;
+        MI355_REQUIRE(!s.weight || (ksplit <= 1 && ((uintptr_t)s.weight & 15) == 0),
+                      "conv_gather: per-problem weights need 16-B alignment and are not available with split-K");
+        d.w = (const unsigned short*)(s.weight ? s.weight : in.weight);
+        d.bias = s.weight ? s.bias : in.bias;
         d.N = s.N; d.H = s.H; d.W = s.W; d.C = s.C; d.P = s.P; d.Q = s.Q; d.sh = s.sh; d.sw = s.sw;
         d.TR = s.TR; d.TS = s.TS; d.dh0 = s.dh0; d.dhs = s.dhs; d.dw0 = s.dw0; d.dws = s.dws;
         d.r0 = s.r0; d.rs = s.rs; d.s0 = s.s0; d.ss = s.ss; d.S = s.S;
@@ -947,7 +953,7 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
             d.out = ws + off;
             d.out_sN = (long long)d.P * d.Q * in.K; d.out_sH = (long long)d.Q * in.K; d.out_sW = in.K;
             d.out_mh = d.out_mw = 1; d.out_oh = d.out_ow = 0;
-            d.addend = nullptr; d.mask = nullptr;
+            d.addend = nullptr; d.mask = nullptr; d.bias = nullptr;
             off += (long long)d.M * in.K;
         }
         L.bias = nullptr; L.act = 0; L.out_f32 = 1;

@@ -196,20 +196,41 @@ __global__ __launch_bounds__(256) void dwconv_fwd_s1_kernel(const unsigned short
 // 16-B cells (consecutive lanes = consecutive cells: conflict-free ds_read_b128), the taps' weights sit in
 // LDS too, and the outputs go back through LDS so that a pixel's NC8 chunks are stored contiguously.
 constexpr int DT_TH = 8, DT_TW = 32, DT_OS = DT_TH * DT_TW + 1;
+// One launch covers up to MI355_DW_MAX_LEVELS feature maps that share the weights (the pyramid levels of an
+// EfficientDet head conv): blockIdx.x walks the 8 x 32 tiles of all the maps, blockIdx.y = (image, chunk group).
+struct DwTileLevel {
+    const unsigned short* in;
+    unsigned short* out;
+    const unsigned short* zin;
+    int H, W, tilesX, tile_begin;
+};
+struct DwTileLaunch {
+    DwTileLevel lv[MI355_DW_MAX_LEVELS];
+    int nlevels, C, nc8, pad_t, pad_l, accumulate;
+};
 template <int K, bool FLIP, bool INSW = false>
-__global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* __restrict__ in, const float* __restrict__ w_t,
-                                                         const float* __restrict__ bias, unsigned short* __restrict__ out,
-                                                         const unsigned short* __restrict__ zin, int accumulate,
-                                                         int N, int H, int W, int C, int nc8, int pad_t, int pad_l) {
+__global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, const float* __restrict__ w_t,
+                                                         const float* __restrict__ bias) {
     constexpr int IH = DT_TH + K - 1, IW = DT_TW + K - 1, NPX = IH * IW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nc8 = L.nc8, C = L.C, pad_t = L.pad_t, pad_l = L.pad_l, accumulate = L.accumulate;
     s8v* tile = reinterpret_cast<s8v*>(smem);                              // [nc8][NPX]
     float* wl = reinterpret_cast<float*>(smem + (size_t)nc8 * NPX * 16);     // [K*K][nc8*8]
     s8v* ot = reinterpret_cast<s8v*>(smem);                                // [nc8][DT_OS] output staging, aliases `tile`
     const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * DT_TW, p0 = blockIdx.y * DT_TH;
+    DwTileLevel P = L.lv[0];
+#pragma unroll
+    for (int i = 1; i < MI355_DW_MAX_LEVELS; ++i)
+        if (i < L.nlevels && (int)blockIdx.x >= L.lv[i].tile_begin) P = L.lv[i];
+    const int tl = blockIdx.x - P.tile_begin;
+    const int tyi = tl / P.tilesX, txi = tl - tyi * P.tilesX;
+    const int q0 = txi * DT_TW, p0 = tyi * DT_TH;
+    const int H = P.H, W = P.W;
+    const unsigned short* __restrict__ in = P.in;
+    unsigned short* __restrict__ out = P.out;
+    const unsigned short* __restrict__ zin = P.zin;
     const int groups = (C >> 3) / nc8;
-    const int n = blockIdx.z / groups, c8b = (blockIdx.z - n * groups) * nc8;
+    const int n = blockIdx.y / groups, c8b = (blockIdx.y - n * groups) * nc8;
     // ---- input halo tile
     for (int i = tid; i < NPX * nc8; i += 256) {
         const int px = i / nc8, ch = i - px * nc8;
@@ -292,23 +313,68 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const unsigned short* _
     }
 }
 
+// levels[i]: x = the map the conv reads (forward: input; data gradient: dy), dy = the map it writes (forward:
+// output; data gradient: dx), aux = zin (data gradient only)
 template <int K, bool FLIP, bool INSW = false>
-static int launch_dw_tile(const void* in, const float* w_t, const float* bias, void* out, const void* zin, int accumulate,
-                          int N, int H, int W, int C, int pad_t, int pad_l, void* stream) {
+static int launch_dw_tile(const Mi355DwLevel* levels, int nlevels, const float* w_t, const float* bias, int accumulate,
+                          int N, int C, int pad_t, int pad_l, void* stream) {
     const int c8n = C / 8;
-    const int nc8 = c8n % 4 == 0 ? 4 : (c8n % 2 == 0 ? 2 : 1);
+    DwTileLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.nlevels = nlevels; L.C = C; L.pad_t = pad_t; L.pad_l = pad_l; L.accumulate = accumulate;
+    L.nc8 = c8n % 4 == 0 ? 4 : (c8n % 2 == 0 ? 2 : 1);
+    long long tiles = 0;
+    for (int i = 0; i < nlevels; ++i) {
+        DwTileLevel& d = L.lv[i];
+        d.in = (const unsigned short*)levels[i].x;  d.out = (unsigned short*)levels[i].dy;
+        d.zin = (const unsigned short*)levels[i].aux;
+        d.H = levels[i].H;  d.W = levels[i].W;
+        d.tilesX = (d.W + DT_TW - 1) / DT_TW;
+        d.tile_begin = (int)tiles;
+        tiles += (long long)d.tilesX * ((d.H + DT_TH - 1) / DT_TH);
+    }
+    MI355_REQUIRE(tiles > 0 && tiles < 0x7fffffffLL && (long long)N * (c8n / L.nc8) <= 65535, "dw_tile: grid");
     constexpr int NPX = (DT_TH + K - 1) * (DT_TW + K - 1);
     static_assert(NPX >= DT_OS, "output staging must fit in the input tile");
-    const size_t lds = (size_t)nc8 * NPX * 16 + (size_t)K * K * nc8 * 32;
-    const dim3 grid((unsigned)((W + DT_TW - 1) / DT_TW), (unsigned)((H + DT_TH - 1) / DT_TH), (unsigned)(N * (c8n / nc8)));
+    const size_t lds = (size_t)L.nc8 * NPX * 16 + (size_t)K * K * L.nc8 * 32;
+    const dim3 grid((unsigned)tiles, (unsigned)(N * (c8n / L.nc8)));
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)dw_tile_s1_kernel<K, FLIP, INSW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((dw_tile_s1_kernel<K, FLIP, INSW>), grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short*)in, w_t,
-                       bias, (unsigned short*)out, (const unsigned short*)zin, accumulate, N, H, W, C, nc8, pad_t, pad_l);
+    hipLaunchKernelGGL((dw_tile_s1_kernel<K, FLIP, INSW>), grid, dim3(256), lds, (hipStream_t)stream, L, w_t, bias);
     return check_launch("dw_tile_s1_kernel");
+}
+
+static bool dw_levels_same_s1(const Mi355DwLevel* lv, int n, int k) {
+    if (!(lv && n >= 1 && n <= MI355_DW_MAX_LEVELS && (k == 3 || k == 5))) return false;
+    for (int i = 0; i < n; ++i)
+        if (!(lv[i].x && lv[i].dy && lv[i].H > 0 && lv[i].W > 0 && lv[i].P == lv[i].H && lv[i].Q == lv[i].W &&
+              lv[i].pad_t == (k - 1) / 2 && lv[i].pad_l == (k - 1) / 2))
+            return false;
+    return true;
+}
+
+extern "C" int mi355_dwconv_fwd_multi(const Mi355DwLevel* levels, int nlevels, int in_swish, const float* w_t,
+                                      const float* bias, int N, int C, int k, void* stream) {
+    MI355_REQUIRE(w_t && N > 0 && C > 0 && C % 8 == 0 && dw_levels_same_s1(levels, nlevels, k),
+                  "dwconv_fwd_multi: stride-1 'same' 3x3 / 5x5 maps only (x = input, dy = output)");
+    const int p = (k - 1) / 2;
+    if (in_swish)
+        return k == 3 ? launch_dw_tile<3, false, true>(levels, nlevels, w_t, bias, 0, N, C, p, p, stream)
+                      : launch_dw_tile<5, false, true>(levels, nlevels, w_t, bias, 0, N, C, p, p, stream);
+    return k == 3 ? launch_dw_tile<3, false>(levels, nlevels, w_t, bias, 0, N, C, p, p, stream)
+                  : launch_dw_tile<5, false>(levels, nlevels, w_t, bias, 0, N, C, p, p, stream);
+}
+
+extern "C" int mi355_dwconv_dgrad_multi(const Mi355DwLevel* levels, int nlevels, const float* w_t, int N, int C, int k,
+                                        int accumulate, void* stream) {
+    MI355_REQUIRE(w_t && N > 0 && C > 0 && C % 8 == 0 && dw_levels_same_s1(levels, nlevels, k),
+                  "dwconv_dgrad_multi: stride-1 'same' 3x3 / 5x5 maps only (x = dy, dy = dx, aux = zin)");
+    const int p = k - 1 - (k - 1) / 2;
+    return k == 3 ? launch_dw_tile<3, true>(levels, nlevels, w_t, nullptr, accumulate, N, C, p, p, stream)
+                  : launch_dw_tile<5, true>(levels, nlevels, w_t, nullptr, accumulate, N, C, p, p, stream);
 }
 
 extern "C" int mi355_dwconv_fwd(const void* in, int in_swish, const float* w_t, const float* bias, void* out,
@@ -317,11 +383,14 @@ extern "C" int mi355_dwconv_fwd(const void* in, int in_swish, const float* w_t, 
     MI355_REQUIRE(in && w_t && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && k > 0 && stride > 0,
                   "dwconv_fwd: bad args");
     if (stride == 1 && (k == 3 || k == 5) && P == H && Q == W && W >= 16 && H >= 8) {
+        Mi355DwLevel lv;
+        memset(&lv, 0, sizeof(lv));
+        lv.x = in; lv.dy = out; lv.H = H; lv.W = W;
         if (in_swish)
-            return k == 3 ? launch_dw_tile<3, false, true>(in, w_t, bias, out, nullptr, 0, N, H, W, C, pad_t, pad_l, stream)
-                          : launch_dw_tile<5, false, true>(in, w_t, bias, out, nullptr, 0, N, H, W, C, pad_t, pad_l, stream);
-        return k == 3 ? launch_dw_tile<3, false>(in, w_t, bias, out, nullptr, 0, N, H, W, C, pad_t, pad_l, stream)
-                      : launch_dw_tile<5, false>(in, w_t, bias, out, nullptr, 0, N, H, W, C, pad_t, pad_l, stream);
+            return k == 3 ? launch_dw_tile<3, false, true>(&lv, 1, w_t, bias, 0, N, C, pad_t, pad_l, stream)
+                          : launch_dw_tile<5, false, true>(&lv, 1, w_t, bias, 0, N, C, pad_t, pad_l, stream);
+        return k == 3 ? launch_dw_tile<3, false>(&lv, 1, w_t, bias, 0, N, C, pad_t, pad_l, stream)
+                      : launch_dw_tile<5, false>(&lv, 1, w_t, bias, 0, N, C, pad_t, pad_l, stream);
     }
     if (stride == 1 && !in_swish && (k == 3 || k == 5) && P == H && Q == W) {
         const long long tot4 = (long long)N * P * ((Q + 3) / 4) * (C / 8);
@@ -471,8 +540,13 @@ extern "C" int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, co
                                   int accumulate, void* stream) {
     MI355_REQUIRE(dy && w_t && dx && N > 0 && C > 0 && C % 8 == 0 && k > 0 && stride > 0, "dwconv_dgrad: bad args");
     if (stride == 1 && (k == 3 || k == 5) && P == H && Q == W && W >= 16 && H >= 8 && pad_t == (k - 1) / 2 && pad_l == (k - 1) / 2)
-        return k == 3 ? launch_dw_tile<3, true>(dy, w_t, nullptr, dx, zin, accumulate, N, H, W, C, k - 1 - pad_t, k - 1 - pad_l, stream)
-                      : launch_dw_tile<5, true>(dy, w_t, nullptr, dx, zin, accumulate, N, H, W, C, k - 1 - pad_t, k - 1 - pad_l, stream);
+    {
+        Mi355DwLevel lv;
+        memset(&lv, 0, sizeof(lv));
+        lv.x = dy; lv.dy = dx; lv.aux = zin; lv.H = H; lv.W = W;
+        return k == 3 ? launch_dw_tile<3, true>(&lv, 1, w_t, nullptr, accumulate, N, C, k - 1 - pad_t, k - 1 - pad_l, stream)
+                      : launch_dw_tile<5, true>(&lv, 1, w_t, nullptr, accumulate, N, C, k - 1 - pad_t, k - 1 - pad_l, stream);
+    }
     if (stride == 2 && (k == 3 || k == 5)) {
         const long long tot4 = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
         if (k == 3)
@@ -764,6 +838,262 @@ extern "C" int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, f
     return check_launch("dwconv_wgrad_kernel");
 }
 
+// LDS-tiled, bit-reproducible depthwise weight gradient (bf16 tensors, k = 3 / 5, stride 1 / 2), one launch for up to
+// MI355_DW_MAX_LEVELS feature maps that share the weight (the pyramid levels of an EfficientDet head conv).  A block
+// owns NC8 8-channel chunks and walks output tiles of 256 pixels (8 x 32, or 16 x 16 for maps <= 16 wide): the
+// activation halo tile (swish applied once per loaded element when the layer stores its pre-activation) and the dy
+// tile are fetched ONCE into [chunk][pixel] planes of 16-B cells (the sliding-window kernel above re-reads both k
+// times through L1/L2 and a thread walks 32 pixels of a row in dependent batches: 30 us for a 64 x 64 x 64 pyramid
+// level against a 4 us floor).  A thread owns (pixel lane of the tile, kernel row a, chunk) and keeps its k taps x 8
+// channels in registers over all the tiles of the block: per step one dy cell and k activation cells (ds_read_b128,
+// lanes = consecutive cells) feed 8 k multiply-adds issued as v_dot2c_f32_bf16 on the packed bf16 pairs with one half
+// of the dy pair masked to zero (no bf16 -> fp32 unpacking: half the vector instructions).  At the end the 32 pixel
+// lanes are summed by shuffles and the block stores ITS partial sums as one row of the layer's slab workspace
+// [slab][(T + 1) * C] (taps, then the dy column sums): plain stores, no atomics, nothing to zero;
+// mi355_dw_param_grads_table adds the rows in index order.
+struct DwWgLevel {
+    const unsigned short* x;
+    const unsigned short* dy;
+    int H, W, P, Q, pad_t, pad_l, tilesX, tilesXY, tile_begin;
+};
+struct DwWgLaunch {
+    DwWgLevel lv[MI355_DW_MAX_LEVELS];
+    int nlevels, ntiles, C, nc8, want_cs;
+};
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2bf(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, a), __builtin_bit_cast(bf2v, b), c, false);
+}
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+template <int K, int S, bool INSW, int TW>
+__global__ __launch_bounds__(32 * K * (K == 3 ? 4 : 2), (S == 2 ? 3 : (K == 3 ? 5 : 4))) void dw_wgrad_tile_kernel(const DwWgLaunch L, float* __restrict__ slabs) {
+    constexpr int TH = 256 / TW, RP = 32 / TW;              // RP tile rows side by side in the 32 pixel lanes
+    constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K, NPX = IH * IW, NOUT = 256;
+    constexpr int UJ = K == 3 ? 1 : 2;                      // unroll of the tile-row loop
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nc8 = L.nc8, C = L.C;
+    u4v* xt = reinterpret_cast<u4v*>(smem);                 // [nc8][NPX]
+    u4v* dt = xt + (size_t)nc8 * NPX;                       // [nc8][NOUT]
+    const int tid = threadIdx.x;
+    const int pl = tid & 31, slot = tid >> 5;               // slot = a * nc8 + ch
+    const int a = slot / nc8, ch = slot - a * nc8;
+    const int prow = pl / TW, pcol = pl - prow * TW;
+    const int c8b = blockIdx.x * nc8;
+    const int sc = tid % nc8, spx = tid / nc8;              // staging: this thread's chunk and first cell, stride 32 K
+    float acc[K][8], cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        cs[e] = 0.0f;
+#pragma unroll
+        for (int b = 0; b < K; ++b) acc[b][e] = 0.0f;
+    }
+    const u4v zero = (u4v){0u, 0u, 0u, 0u};
+    for (int t = blockIdx.y; t < L.ntiles; t += gridDim.y) {
+        DwWgLevel P = L.lv[0];
+#pragma unroll
+        for (int i = 1; i < MI355_DW_MAX_LEVELS; ++i)
+            if (i < L.nlevels && t >= L.lv[i].tile_begin) P = L.lv[i];
+        const int tl = t - P.tile_begin;
+        const int n = tl / P.tilesXY, r = tl - n * P.tilesXY;
+        const int tyi = r / P.tilesX, txi = r - tyi * P.tilesX;
+        const int p0 = tyi * TH, q0 = txi * TW;
+        const int h0 = p0 * S - P.pad_t, w0 = q0 * S - P.pad_l;
+        const unsigned short* xb = P.x + (long long)n * P.H * P.W * C + (c8b + sc) * 8;
+        const unsigned short* gb = P.dy + (long long)n * P.P * P.Q * C + (c8b + sc) * 8;
+        // every load of the tile is issued before the first use (a load -> swish -> LDS store loop is one HBM round
+        // trip per cell: 22 us per tile)
+        constexpr int XI = (NPX + 32 * K - 1) / (32 * K), GI = (NOUT + 32 * K - 1) / (32 * K);   // sstep == 32 K
+        u4v xr[XI], gr[GI];
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int px = spx + i * (32 * K);
+            const int iy = px / IW, ix = px - iy * IW;
+            const int h = h0 + iy, w = w0 + ix;
+            xr[i] = zero;
+            if (px < NPX && (unsigned)h < (unsigned)P.H && (unsigned)w < (unsigned)P.W)
+                xr[i] = *reinterpret_cast<const u4v*>(xb + ((long long)h * P.W + w) * C);
+        }
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int px = spx + i * (32 * K);
+            const int p = p0 + px / TW, q = q0 + (px & (TW - 1));
+            gr[i] = zero;
+            if (px < NOUT && p < P.P && q < P.Q) gr[i] = *reinterpret_cast<const u4v*>(gb + ((long long)p * P.Q + q) * C);
+        }
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int px = spx + i * (32 * K);
+            u4v v = xr[i];
+            if (INSW) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = swishf(__uint_as_float(v[e] << 16)), hi = swishf(__uint_as_float(v[e] & 0xffff0000u));
+                    v[e] = (unsigned)f32_to_bf16_rn(lo) | ((unsigned)f32_to_bf16_rn(hi) << 16);
+                }
+            }
+            if (px < NPX) xt[sc * NPX + px] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+            const int px = spx + i * (32 * K);
+            if (px < NOUT) dt[sc * NOUT + px] = gr[i];
+        }
+        __syncthreads();
+        if (a < K) {
+            // (fully unrolled, hipcc hoists all 8 (1 + K) ds_read_b128 and spills 130-350 VGPRs)
+#pragma unroll UJ
+            for (int j = 0; j < TH / RP; ++j) {
+                const int p = j * RP + prow;
+                const u4v gv = dt[ch * NOUT + p * TW + pcol];
+                unsigned glo[4], ghi[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { glo[e] = gv[e] & 0x0000ffffu; ghi[e] = gv[e] & 0xffff0000u; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {               // (every kernel row keeps the sums, row 0 stores them)
+                    cs[2 * e] += __uint_as_float(gv[e] << 16);
+                    cs[2 * e + 1] += __uint_as_float(ghi[e]);
+                }
+#pragma unroll
+                for (int b = 0; b < K; ++b) {
+                    const u4v xv = xt[ch * NPX + (p * S + a) * IW + pcol * S + b];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[b][2 * e] = dot2bf(xv[e], glo[e], acc[b][2 * e]);
+                        acc[b][2 * e + 1] = dot2bf(xv[e], ghi[e], acc[b][2 * e + 1]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the 32 pixel lanes of a (kernel row, chunk) slot are the 32 lanes of a half wave
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) cs[e] += __shfl_xor(cs[e], o, 64);
+#pragma unroll
+        for (int b = 0; b < K; ++b)
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) acc[b][e] += __shfl_xor(acc[b][e], o, 64);
+    }
+    if (pl == 0 && a < K) {
+        float* row = slabs + (long long)blockIdx.y * (K * K + 1) * C + (c8b + ch) * 8;
+#pragma unroll
+        for (int b = 0; b < K; ++b) {
+            float* dst = row + (a * K + b) * C;
+            reinterpret_cast<float4*>(dst)[0] = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+            reinterpret_cast<float4*>(dst)[1] = make_float4(acc[b][4], acc[b][5], acc[b][6], acc[b][7]);
+        }
+        if (a == 0 && L.want_cs) {
+            float* dst = row + K * K * C;
+            reinterpret_cast<float4*>(dst)[0] = make_float4(cs[0], cs[1], cs[2], cs[3]);
+            reinterpret_cast<float4*>(dst)[1] = make_float4(cs[4], cs[5], cs[6], cs[7]);
+        }
+    }
+}
+
+// launch geometry shared by mi355_dwconv_wgrad_nslabs* and mi355_dwconv_wgrad_slabs*
+static bool dw_wgrad_geometry(const Mi355DwLevel* lv, int nlevels, int N, int C, int k, int stride, DwWgLaunch* L,
+                              int* tw, int* nslabs) {
+    if (!(lv && nlevels >= 1 && nlevels <= MI355_DW_MAX_LEVELS && (k == 3 || k == 5) && (stride == 1 || stride == 2) &&
+          C > 0 && C % 8 == 0 && N > 0))
+        return false;
+    const int c8n = C / 8, lim = (k == 3 ? 4 : 2) / stride;   // stride 2: the halo tile is four times the pixels
+    int g = 1;
+    for (int d = lim; d >= 1; --d)
+        if (c8n % d == 0) { g = d; break; }
+    int maxq = 0;
+    for (int i = 0; i < nlevels; ++i) maxq = lv[i].Q > maxq ? lv[i].Q : maxq;
+    *tw = maxq > 16 ? 32 : 16;
+    const int th = 256 / *tw;
+    long long nt = 0;
+    for (int i = 0; i < nlevels; ++i) {
+        if (!(lv[i].P > 0 && lv[i].Q > 0 && lv[i].H > 0 && lv[i].W > 0)) return false;
+        if ((long long)N * lv[i].H * lv[i].W * C >= 0x7fffffffLL * 4LL) return false;
+        const int tX = (lv[i].Q + *tw - 1) / *tw, tY = (lv[i].P + th - 1) / th;
+        if (L) {
+            DwWgLevel& d = L->lv[i];
+            d.x = (const unsigned short*)lv[i].x; d.dy = (const unsigned short*)lv[i].dy;
+            d.H = lv[i].H; d.W = lv[i].W; d.P = lv[i].P; d.Q = lv[i].Q; d.pad_t = lv[i].pad_t; d.pad_l = lv[i].pad_l;
+            d.tilesX = tX; d.tilesXY = tX * tY; d.tile_begin = (int)nt;
+        }
+        nt += (long long)N * tX * tY;
+    }
+    if (nt > 0x7fffffffLL) return false;
+    const int groups = c8n / g;
+    int cap = 1536 / groups;                                // ~1536 blocks per launch, 16 .. 512 slab rows
+    if (cap > 512) cap = 512;
+    if (cap < 16) cap = 16;
+    *nslabs = nt < cap ? (int)nt : cap;
+    if (L) { L->nlevels = nlevels; L->ntiles = (int)nt; L->C = C; L->nc8 = g; }
+    return true;
+}
+
+extern "C" int mi355_dwconv_wgrad_nslabs_multi(const Mi355DwLevel* levels, int nlevels, int N, int C, int k, int stride,
+                                               int* nslabs) {
+    int tw;
+    MI355_REQUIRE(nslabs && dw_wgrad_geometry(levels, nlevels, N, C, k, stride, nullptr, &tw, nslabs),
+                  "dwconv_wgrad_nslabs: k must be 3 or 5, stride 1 or 2, C %% 8 == 0, 1..%d levels", MI355_DW_MAX_LEVELS);
+    return MI355_OK;
+}
+
+extern "C" int mi355_dwconv_wgrad_nslabs(int N, int C, int k, int stride, int P, int Q, int* nslabs) {
+    Mi355DwLevel lv;
+    memset(&lv, 0, sizeof(lv));
+    lv.H = lv.W = 1; lv.P = P; lv.Q = Q;
+    return mi355_dwconv_wgrad_nslabs_multi(&lv, 1, N, C, k, stride, nslabs);
+}
+
+template <int K, int S, bool INSW, int TW>
+static void launch_dw_wgrad_tile(const DwWgLaunch& L, float* slabs, int nslabs, void* stream) {
+    constexpr int TH = 256 / TW;
+    constexpr int NPX = ((TH - 1) * S + K) * ((TW - 1) * S + K);
+    const size_t lds = (size_t)L.nc8 * (NPX + 256) * 16;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)dw_wgrad_tile_kernel<K, S, INSW, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((dw_wgrad_tile_kernel<K, S, INSW, TW>), dim3((unsigned)(L.C / 8 / L.nc8), (unsigned)nslabs),
+                       dim3(32 * K * L.nc8), lds, (hipStream_t)stream, L, slabs);
+}
+
+extern "C" int mi355_dwconv_wgrad_slabs_multi(const Mi355DwLevel* levels, int nlevels, int in_swish, float* slabs,
+                                              int want_colsum, int N, int C, int k, int stride, void* stream) {
+    DwWgLaunch L;
+    memset(&L, 0, sizeof(L));
+    int tw, nslabs;
+    MI355_REQUIRE(slabs && dw_wgrad_geometry(levels, nlevels, N, C, k, stride, &L, &tw, &nslabs),
+                  "dwconv_wgrad_slabs: k must be 3 or 5, stride 1 or 2, C %% 8 == 0, 1..%d levels", MI355_DW_MAX_LEVELS);
+    for (int i = 0; i < nlevels; ++i) MI355_REQUIRE(levels[i].x && levels[i].dy, "dwconv_wgrad_slabs: level %d null x / dy", i);
+    L.want_cs = want_colsum;
+#define MI355_DWT2(KK, SS, SW)                                                                         \
+    do {                                                                                               \
+        if (tw == 32) launch_dw_wgrad_tile<KK, SS, SW, 32>(L, slabs, nslabs, stream);                  \
+        else launch_dw_wgrad_tile<KK, SS, SW, 16>(L, slabs, nslabs, stream);                           \
+    } while (0)
+#define MI355_DWT(KK, SS)                                                                              \
+    do {                                                                                               \
+        if (in_swish) MI355_DWT2(KK, SS, true); else MI355_DWT2(KK, SS, false);                        \
+    } while (0)
+    if (k == 3 && stride == 1) MI355_DWT(3, 1);
+    else if (k == 3) MI355_DWT(3, 2);
+    else if (stride == 1) MI355_DWT(5, 1);
+    else MI355_DWT(5, 2);
+#undef MI355_DWT
+#undef MI355_DWT2
+    return check_launch("dw_wgrad_tile_kernel");
+}
+
+extern "C" int mi355_dwconv_wgrad_slabs(const void* x, int in_swish, const void* dy, float* slabs, int want_colsum,
+                                        int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P,
+                                        int Q, void* stream) {
+    Mi355DwLevel lv;
+    lv.x = x; lv.dy = dy; lv.aux = nullptr; lv.H = H; lv.W = W; lv.P = P; lv.Q = Q; lv.pad_t = pad_t; lv.pad_l = pad_l;
+    return mi355_dwconv_wgrad_slabs_multi(&lv, 1, in_swish, slabs, want_colsum, N, C, k, stride, stream);
+}
+
 // a = swish(z), materialised once when several taps would otherwise recompute it (dw wgrad)
 __global__ void swish_bf16_kernel(const unsigned short* __restrict__ z, unsigned short* __restrict__ a, long long n8) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -805,29 +1135,61 @@ __global__ void dw_param_grads_kernel(const float* __restrict__ G_t, const float
 }
 
 // All depthwise layers of a plan in ONE launch: blockIdx.y = row of the device-resident descriptor table
-// (48 launches of ~10 us each at the end of the EfficientDet-D0 backward otherwise).
-__global__ void dw_param_grads_table_kernel(const Mi355DwGradDesc* __restrict__ table) {
+// (48 launches of ~10 us each at the end of the EfficientDet-D0 backward otherwise).  A layer's tap sums G_t and dy
+// column sums arrive as `nslabs` partial rows `slab_stride` floats apart (mi355_dwconv_wgrad_slabs; 1 row for the
+// atomic path): a block owns 64 channels, its four 64-lane parts each add a contiguous quarter of the rows in index
+// order and the quarters are combined in a fixed order: bit-reproducible.
+constexpr int DWG_MAXT = 25;
+__global__ __launch_bounds__(256) void dw_param_grads_table_kernel(const Mi355DwGradDesc* __restrict__ table) {
+    __shared__ float s_part[3][DWG_MAXT + 1][64];
     const Mi355DwGradDesc d = table[blockIdx.y];
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d.C) return;
+    if ((int)blockIdx.x * 64 >= d.C) return;                  // (uniform per block)
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool live = c < d.C;
+    const int nsl = d.nslabs > 0 ? d.nslabs : 1;
+    const int lo = (int)((long long)nsl * part / 4), hi = (int)((long long)nsl * (part + 1) / 4);
+    float g[DWG_MAXT + 1];
+#pragma unroll
+    for (int t = 0; t <= DWG_MAXT; ++t) g[t] = 0.0f;
+    if (live) {
+        for (int sl = lo; sl < hi; ++sl) {
+            const float* row = d.G_t + (long long)sl * d.slab_stride;
+#pragma unroll
+            for (int t = 0; t < DWG_MAXT; ++t)
+                if (t < d.T) g[t] += row[t * d.C + c];
+            if (d.colsum) g[DWG_MAXT] += d.colsum[(long long)sl * d.slab_stride + c];
+        }
+    }
+    if (part > 0) {
+#pragma unroll
+        for (int t = 0; t <= DWG_MAXT; ++t) s_part[part - 1][t][cl] = g[t];
+    }
+    __syncthreads();
+    if (part != 0 || !live) return;
+#pragma unroll
+    for (int t = 0; t <= DWG_MAXT; ++t) g[t] = ((g[t] + s_part[0][t][cl]) + s_part[1][t][cl]) + s_part[2][t][cl];
     const float sc = d.scale ? d.scale[c] : 1.0f;
     float dot = 0.0f;
-    for (int t = 0; t < d.T; ++t) {
-        const float g = d.G_t[t * d.C + c];
-        dot += d.w[c * d.T + t] * g;
-        const float v = g * sc;
-        d.dW[c * d.T + t] = d.accumulate ? d.dW[c * d.T + t] + v : v;
+#pragma unroll
+    for (int t = 0; t < DWG_MAXT; ++t) {
+        if (t < d.T) {
+            dot += d.w[c * d.T + t] * g[t];
+            const float v = g[t] * sc;
+            d.dW[c * d.T + t] = d.accumulate ? d.dW[c * d.T + t] + v : v;
+        }
     }
+    const float csum = g[DWG_MAXT];
     if (d.dgamma) {
-        const float dg = (1.0f / sqrtf(d.var[c] + d.eps)) * (dot - d.mean[c] * d.colsum[c]);
+        const float dg = (1.0f / sqrtf(d.var[c] + d.eps)) * (dot - d.mean[c] * csum);
         d.dgamma[c] = d.accumulate ? d.dgamma[c] + dg : dg;
     }
-    if (d.dbeta) d.dbeta[c] = d.accumulate ? d.dbeta[c] + d.colsum[c] : d.colsum[c];
+    if (d.dbeta) d.dbeta[c] = d.accumulate ? d.dbeta[c] + csum : csum;
 }
 
 extern "C" int mi355_dw_param_grads_table(const Mi355DwGradDesc* table, int n, int max_c, void* stream) {
     MI355_REQUIRE(table && n > 0 && n <= 65535 && max_c > 0, "dw_param_grads_table: bad args");
-    hipLaunchKernelGGL(dw_param_grads_table_kernel, dim3(blocks_for(max_c), (unsigned)n), dim3(256), 0,
+    hipLaunchKernelGGL(dw_param_grads_table_kernel, dim3((unsigned)((max_c + 63) / 64), (unsigned)n), dim3(256), 0,
                        (hipStream_t)stream, table);
     return check_launch("dw_param_grads_table_kernel");
 }
@@ -897,7 +1259,9 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const T* __restrict__ a,
 }
 
 static void se_grid(int N, int HW, int* rows, dim3* grid) {
-    int slabs = (2048 + N - 1) / N;                      // ~2048 blocks in total
+    // ~512 blocks in total: the per-sample FC kernels add the slab partials with C threads, 128 slabs per sample
+    // (2048 blocks) made that sum a third of their 23-32 us
+    int slabs = (512 + N - 1) / N;
     if (slabs > (HW + 63) / 64) slabs = (HW + 63) / 64;  // >= 64 rows per block
     if (slabs < 1) slabs = 1;
     *rows = (HW + slabs - 1) / slabs;
@@ -955,17 +1319,26 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pa
     __syncthreads();
     // squeeze: one wave per reduced channel j, lanes stride over c (coalesced rows of w1), shuffle reduction
     // (a thread per j walked its own 1152-float row: 32 us of dependent loads for 55 k MACs)
+    // (four rows per wave and round: their loads and shuffle chains overlap; one row per round was 12 dependent rounds
+    //  for the 48 x 1152 layers)
     const int wave = tid >> 6, lane = tid & 63;
-    for (int j = wave; j < Cse; j += 4) {
-        float t = 0.0f;
-#pragma unroll 4
-        for (int c = lane; c < C; c += 64) t += w1[j * C + c] * s_pool[c];
+    for (int j0 = wave * 4; j0 < Cse; j0 += 16) {
+        float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int c = lane; c < C; c += 64) {
+            const float pv = s_pool[c];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-        if (lane == 0) {
-            t += b1[j];
-            rpre[(long long)n * Cse + j] = t;
-            s_r[j] = swishf_exact(t);
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u < Cse) t[u] += w1[(j0 + u) * C + c] * pv;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t[u] += __shfl_xor(t[u], o, 64);
+            if (lane == 0 && j0 + u < Cse) {
+                const float v = t[u] + b1[j0 + u];
+                rpre[(long long)n * Cse + j0 + u] = v;
+                s_r[j0 + u] = swishf_exact(v);
+            }
         }
     }
     __syncthreads();
@@ -1071,6 +1444,106 @@ extern "C" int mi355_se_fc_bwd(const float* pool, const float* w1, const float* 
     hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(N, slices), dim3(256), (size_t)(2 * C + 2 * Cse) * 4, (hipStream_t)stream, pool,
                        w1, w2, rpre, gate, ggate, slabs, gpool, dw1, db1, dw2, db2, C, Cse);
     return check_launch("se_fc_bwd_kernel");
+}
+
+// The same backward without atomics, in two parts.  (1) per sample, the DATA path only: de = ggate * gate (1 - gate),
+// dr = (W2^T de) * swish'(rpre), gpool = W1^T dr; grid (N, parts): every block rebuilds de and dr (a few 10 k MACs)
+// and owns 1/parts of gpool.  dr: lanes = reduced channels j (rows of W2 are Cse contiguous floats: coalesced, no
+// shuffles), the 8 waves split the C channels and their partials are added in wave order.  de and dr are kept for
+// (2) mi355_se_param_grads_table: all squeeze-excite layers of a plan in ONE launch at the end of the backward,
+// a thread per parameter element sums over the N samples in index order: bit-reproducible (the atomic form above
+// issued 2 C Cse atomics per sample: 1.8 M for the 1152 x 48 layers of a batch of 16).
+__global__ __launch_bounds__(512) void se_fc_bwd_data_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                             const float* __restrict__ rpre, const float* __restrict__ gate,
+                                                             const float* __restrict__ ggate, int slabs,
+                                                             float* __restrict__ de_out, float* __restrict__ dr_out,
+                                                             float* __restrict__ gpool, int C, int Cse) {
+    extern __shared__ float sm[];                  // de[C] | dr[Cse] | wave partials [8][64]
+    float* s_de = sm;
+    float* s_dr = sm + C;
+    float* s_wp = sm + C + Cse;
+    const int n = blockIdx.x, tid = threadIdx.x, part = blockIdx.y, parts = gridDim.y;
+    for (int c = tid; c < C; c += 512) {
+        const float g = gate[(long long)n * C + c];
+        float gg = 0.0f;
+#pragma unroll 8
+        for (int sl = 0; sl < slabs; ++sl) gg += ggate[((long long)n * slabs + sl) * C + c];   // fixed order
+        const float de = gg * g * (1.0f - g);
+        s_de[c] = de;
+        if (part == 0) de_out[(long long)n * C + c] = de;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    const int cw = (C + 7) / 8, c_lo = wave * cw, c_hi = min(C, c_lo + cw);
+    for (int j0 = 0; j0 < Cse; j0 += 64) {
+        const int j = j0 + lane;
+        float t = 0.0f;
+        if (j < Cse) {
+#pragma unroll 8
+            for (int c = c_lo; c < c_hi; ++c) t += w2[c * Cse + j] * s_de[c];
+        }
+        s_wp[wave * 64 + lane] = t;
+        __syncthreads();
+        if (wave == 0 && j < Cse) {
+            float v = s_wp[lane];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) v += s_wp[w * 64 + lane];
+            const float d = v * dswishf_exact(rpre[(long long)n * Cse + j]);
+            s_dr[j] = d;
+            if (part == 0) dr_out[(long long)n * Cse + j] = d;
+        }
+        __syncthreads();
+    }
+    const int cl = (int)((long long)C * part / parts), ch = (int)((long long)C * (part + 1) / parts);
+    for (int c = cl + tid; c < ch; c += 512) {
+        float t = 0.0f;
+#pragma unroll 8
+        for (int j = 0; j < Cse; ++j) t += w1[j * C + c] * s_dr[j];
+        gpool[(long long)n * C + c] = t;
+    }
+}
+
+extern "C" int mi355_se_fc_bwd_data(const float* w1, const float* w2, const float* rpre, const float* gate,
+                                    const float* ggate, int slabs, float* de, float* dr, float* gpool, int N, int C,
+                                    int Cse, void* stream) {
+    MI355_REQUIRE(w1 && w2 && rpre && gate && ggate && slabs > 0 && de && dr && gpool && N > 0 && C > 0 && Cse > 0,
+                  "se_fc_bwd_data: bad args");
+    const int parts = C >= 512 ? 4 : (C >= 128 ? 2 : 1);
+    hipLaunchKernelGGL(se_fc_bwd_data_kernel, dim3(N, parts), dim3(512), (size_t)(C + Cse + 512) * 4, (hipStream_t)stream,
+                       w1, w2, rpre, gate, ggate, slabs, de, dr, gpool, C, Cse);
+    return check_launch("se_fc_bwd_data_kernel");
+}
+
+__global__ void se_param_grads_table_kernel(const Mi355SeGradDesc* __restrict__ table) {
+    const Mi355SeGradDesc d = table[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int CC = d.C * d.Cse;
+    if (i >= 2 * CC + d.C + d.Cse) return;
+    float t = 0.0f;
+    if (i < CC) {                                  // dw2[c][j] = sum_n de[n][c] * swish(rpre[n][j])
+        const int c = i / d.Cse, j = i - c * d.Cse;
+        for (int n = 0; n < d.N; ++n) t += d.de[(long long)n * d.C + c] * swishf_exact(d.rpre[(long long)n * d.Cse + j]);
+        d.dw2[i] = t;
+    } else if (i < 2 * CC) {                       // dw1[j][c] = sum_n dr[n][j] * pool[n][c]
+        const int k = i - CC, j = k / d.C, c = k - j * d.C;
+        for (int n = 0; n < d.N; ++n) t += d.dr[(long long)n * d.Cse + j] * d.pool[(long long)n * d.C + c];
+        d.dw1[k] = t;
+    } else if (i < 2 * CC + d.C) {                 // db2[c] = sum_n de[n][c]
+        const int c = i - 2 * CC;
+        for (int n = 0; n < d.N; ++n) t += d.de[(long long)n * d.C + c];
+        d.db2[c] = t;
+    } else {                                       // db1[j] = sum_n dr[n][j]
+        const int j = i - 2 * CC - d.C;
+        for (int n = 0; n < d.N; ++n) t += d.dr[(long long)n * d.Cse + j];
+        d.db1[j] = t;
+    }
+}
+
+extern "C" int mi355_se_param_grads_table(const Mi355SeGradDesc* table, int n, int max_elems, void* stream) {
+    MI355_REQUIRE(table && n > 0 && n <= 65535 && max_elems > 0, "se_param_grads_table: bad args");
+    hipLaunchKernelGGL(se_param_grads_table_kernel, dim3(blocks_for(max_elems), (unsigned)n), dim3(256), 0,
+                       (hipStream_t)stream, table);
+    return check_launch("se_param_grads_table_kernel");
 }
 
 template <typename T>

@@ -19,7 +19,7 @@ import os
 
 import torch
 
-from . import _lib, ops_conv, ops_detect
+from . import _lib, ops_conv, ops_detect, ops_effdet
 from ._lib import c_f32, c_i64, c_int, c_vp, ptr
 from .engine import LayerSpec, RetinaPlan
 from .ops_conv import ACT_NONE, ACT_SIGMOID, ConvProblem, dgrad_problems, fwd_problem
@@ -36,12 +36,19 @@ class DwSpec(object):
         self.stride = conv.stride[0]
         self.T = self.k * self.k
         self.w_t = self.scale = self.shift = self.G_t = self.colsum = None
+        self.nslabs, self.slabs = 0, None       # partial-sum rows of the weight gradient (mi355_dwconv_wgrad_slabs)
 
 
 class DwGradDesc(ctypes.Structure):
     """Mi355DwGradDesc (include/mi355det_effdet.h)."""
     _fields_ = [(n, c_vp) for n in ('G_t', 'w', 'scale', 'colsum', 'mean', 'var', 'dW', 'dgamma', 'dbeta')] + \
-               [('eps', c_f32), ('C', c_int), ('T', c_int), ('accumulate', c_int)]
+               [('eps', c_f32), ('C', c_int), ('T', c_int), ('accumulate', c_int), ('nslabs', c_int), ('slab_stride', c_int)]
+
+
+class SeGradDesc(ctypes.Structure):
+    """Mi355SeGradDesc (include/mi355det_effdet.h)."""
+    _fields_ = [(n, c_vp) for n in ('pool', 'rpre', 'de', 'dr', 'dw1', 'db1', 'dw2', 'db2')] + \
+               [('N', c_int), ('C', c_int), ('Cse', c_int), ('pad_', c_int)]
 
 
 class DwPrepDesc(ctypes.Structure):
@@ -224,18 +231,125 @@ class EffDetPlan(RetinaPlan):
         self._step(self.fwd_steps, 'mi355_dwconv_fwd', ptr(xs), c_int(insw), ptr(spec.w_t), ptr(spec.shift),
                    ptr(out), *geo)
 
+        # bf16 plans: bit-reproducible weight gradient, every launch of the layer (the pyramid levels of a shared head
+        # conv) stores its own partial rows of the layer's slab workspace; fp32 plans: the generic atomic kernel
+        slab_base = None
+        if self.prec != 'fp32' and spec.k in (3, 5) and spec.stride in (1, 2):
+            slab_base = spec.nslabs
+            spec.nslabs += ops_effdet.dwconv_wgrad_nslabs(N, C, spec.k, spec.stride, P, Q)
+
         def bwd():
             if not self.has_grad(out):
                 return
             dy = self.grad(out)
-            self._step(self.bwd_steps, 'mi355_dwconv_wgrad', ptr(xs), c_int(insw), ptr(dy), ptr(spec.G_t),
-                       ptr(spec.colsum if spec.bn is not None else None), *geo)
+            if slab_base is not None:
+                row = (spec.T + 1) * C
+                if spec.slabs is None:                      # all forward launches of the layer are known by now
+                    spec.slabs = self.new((spec.nslabs, row), torch.float32, zero=True)
+                self._step(self.bwd_steps, 'mi355_dwconv_wgrad_slabs', ptr(xs), c_int(insw), ptr(dy),
+                           c_vp(spec.slabs.data_ptr() + slab_base * row * 4),
+                           c_int(int(spec.bn is not None)), *geo)
+            else:
+                self._dw_atomic = True                      # dw_scratch is accumulated into: cleared every step
+                self._step(self.bwd_steps, 'mi355_dwconv_wgrad', ptr(xs), c_int(insw), ptr(dy), ptr(spec.G_t),
+                           ptr(spec.colsum if spec.bn is not None else None), *geo)
             dx = self.grad(x)
             acc = not self.first_write(x)
             self._step(self.bwd_steps, 'mi355_dwconv_dgrad', ptr(dy), ptr(spec.w_t), ptr(dx),
                        ptr(x if x_swish else None), *(geo + (c_int(int(acc)),)))
         self.tape.append(bwd)
         return out
+
+    def pw_multi_op(self, specs, xs):
+        """The pointwise conv of a head layer on every pyramid level: the levels share the conv but fold their own
+        BatchNorm (efficientdet.py:335-353, bn_list[level][i]), so each problem of the grouped launch brings its own
+        folded weights / bias (Mi355ConvProblem.weight).  One forward, one weight-gradient (per-level workspaces,
+        mi355_conv_wgrad_multi) and one data-gradient launch instead of one of each per level."""
+        if self.prec == 'fp32' or not self.deterministic or len(xs) < 2 or len(xs) > ops_conv.MAX_PROBLEMS or \
+                any(sp.bn_train or sp.stride != 1 for sp in specs) or os.environ.get('MI355_EFF_GROUP_PW', '1') == '0':
+            return [self.pw_op(sp, x) for sp, x in zip(specs, xs)]
+        s0 = specs[0]
+        outs, probs, geo = [], [], []
+        for sp, x in zip(specs, xs):
+            N, H, W, C = x.shape
+            assert C == sp.Cpad and (sp.K, sp.Cpad, sp.T) == (s0.K, s0.Cpad, s0.T), sp.name
+            pt, pl, P, Q = sp.geometry(H, W)
+            out = self.new((N, P, Q, sp.Kpad), zero=sp.Kpad != sp.K)
+            pr = fwd_problem(x, out.data_ptr(), sp.R, sp.S, sp.stride, (pt, pl), K=sp.K, out_size=(P, Q),
+                             out_strides=(P * Q * sp.Kpad, Q * sp.Kpad, sp.Kpad))
+            pr.weight = sp.w_fwd.data_ptr()
+            pr.bias = 0 if sp.bias_tensor is None else sp.bias_tensor.data_ptr()
+            probs.append(pr)
+            outs.append(out)
+            geo.append((N, H, W, pt, pl, P, Q))
+            self.fwd_launches.append((sp, [(N, P, Q)]))
+        self._gather(self.fwd_steps, probs, s0.w_fwd, s0.K, s0.T, bias=s0.bias_tensor)
+
+        def bwd():
+            live = [self.has_grad(o) for o in outs]
+            if not any(live):
+                return
+            assert all(live), 'a head conv with gradient on some of its levels only'
+            dys = [self.grad(o) for o in outs]
+            group = []
+            for sp, x, dy, (N, H, W, pt, pl, P, Q) in zip(specs, xs, dys, geo):
+                wp = fwd_problem(x, dy.data_ptr(), sp.R, sp.S, sp.stride, (pt, pl), K=sp.Kpad, out_size=(P, Q))
+                group.append((wp, sp, N * P * Q))
+            self._wgrad_multi(group)
+            if not all(sp.need_dgrad for sp in specs):
+                return
+            dprobs = []
+            for sp, x, dy, (N, H, W, pt, pl, P, Q) in zip(specs, xs, dys, geo):
+                dx = self.grad(x)
+                acc = not self.first_write(x)
+                ps = dgrad_problems(dy, dx.data_ptr(), H, W, sp.Cpad, sp.R, sp.S, sp.stride, pt,
+                                    addend=dx if acc else None)
+                assert len(ps) == 1
+                ps[0].weight, ps[0].bias = sp.w_dgr.data_ptr(), 0
+                dprobs.append(ps[0])
+            self._gather(self.bwd_steps, dprobs, s0.w_dgr, s0.Cpad, s0.T)
+        self.tape.append(bwd)
+        return outs
+
+    def dw_multi_op(self, spec, xs, x_swish):
+        """The same depthwise conv applied to several feature maps (the pyramid levels of a head conv,
+        efficientdet.py:335-353): ONE forward launch, ONE weight-gradient launch (partial rows summed over all the
+        levels) and ONE data-gradient launch instead of one of each per level."""
+        if self.prec == 'fp32' or spec.stride != 1 or spec.k not in (3, 5) or not (2 <= len(xs) <= 5):
+            return [self.dw_op(spec, x, x_swish) for x in xs]
+        N, C = xs[0].shape[0], xs[0].shape[3]
+        outs = [self.new(tuple(x.shape)) for x in xs]
+        insw, nl = int(bool(x_swish)), len(xs)
+        arr = ops_effdet.dw_levels(list(zip(xs, outs)), spec.k, 1)
+        self._step(self.fwd_steps, 'mi355_dwconv_fwd_multi', arr, c_int(nl), c_int(insw), ptr(spec.w_t),
+                   ptr(spec.shift), c_int(N), c_int(C), c_int(spec.k))
+        ns = ctypes.c_int()
+        _lib.call('mi355_dwconv_wgrad_nslabs_multi', arr, c_int(nl), c_int(N), c_int(C), c_int(spec.k), c_int(1),
+                  ctypes.byref(ns))
+        slab_base = spec.nslabs
+        spec.nslabs += ns.value
+
+        def bwd():
+            live = [self.has_grad(o) for o in outs]
+            if not any(live):
+                return
+            assert all(live), 'a shared depthwise conv with gradient on some of its maps only'
+            dys = [self.grad(o) for o in outs]
+            row = (spec.T + 1) * C
+            if spec.slabs is None:
+                spec.slabs = self.new((spec.nslabs, row), torch.float32, zero=True)
+            warr = ops_effdet.dw_levels(list(zip(xs, dys)), spec.k, 1)
+            self._step(self.bwd_steps, 'mi355_dwconv_wgrad_slabs_multi', warr, c_int(nl), c_int(insw),
+                       c_vp(spec.slabs.data_ptr() + slab_base * row * 4), c_int(int(spec.bn is not None)),
+                       c_int(N), c_int(C), c_int(spec.k), c_int(1))
+            dxs = [self.grad(x) for x in xs]
+            accs = [not self.first_write(x) for x in xs]
+            assert len(set(accs)) == 1, 'levels of one launch must all overwrite or all accumulate'
+            garr = ops_effdet.dw_levels([(dy, dx, x if x_swish else None) for dy, dx, x in zip(dys, dxs, xs)], spec.k, 1)
+            self._step(self.bwd_steps, 'mi355_dwconv_dgrad_multi', garr, c_int(nl), ptr(spec.w_t), c_int(N), c_int(C),
+                       c_int(spec.k), c_int(int(accs[0])))
+        self.tape.append(bwd)
+        return outs
 
     def se_op(self, spec, z):
         N, H, W, C = z.shape
@@ -262,8 +376,13 @@ class EffDetPlan(RetinaPlan):
             ggate = self.new((N, slabs, C), torch.float32)
             gpool = self.new((N, C), torch.float32)
             self._step(self.bwd_steps, 'mi355_se_bwd_reduce', ptr(gu), ptr(z), ptr(ggate), *dims)
-            self._se_bwd.append((spec, pool, rpre, gate, ggate, gpool, N, slabs))
-            self._step(self.bwd_steps, '__se_fc_bwd__', len(self._se_bwd) - 1)
+            # data path per sample now; the FC parameter gradients of all squeeze-excite layers in one table launch at
+            # the end of the backward (_extra_param_grads): no atomics, bit-reproducible
+            de = self.new((N, C), torch.float32)
+            dr = self.new((N, spec.Cse), torch.float32)
+            self._se_bwd.append((spec, pool, rpre, de, dr, N))
+            self._step(self.bwd_steps, 'mi355_se_fc_bwd_data', ptr(w1), ptr(w2), ptr(rpre), ptr(gate), ptr(ggate),
+                       c_int(slabs), ptr(de), ptr(dr), ptr(gpool), c_int(N), c_int(C), c_int(spec.Cse))
             gz = self.grad(z)
             assert self.first_write(z)
             self._step(self.bwd_steps, 'mi355_se_bwd_apply', ptr(gu), ptr(z), ptr(gate), ptr(gpool), ptr(gz), *dims)
@@ -499,25 +618,40 @@ class EffDetPlan(RetinaPlan):
         the [B, A, .] layout and takes the loss gradient from the padded cell rows of `gout`."""
         B = self.B
         per_img = self.ncells * kout
-        for lvl, f in enumerate(self.levels):
-            sw = False
-            for i in range(len(rec['dw'])):
-                f = self.pw_op(rec['pw'][lvl][i], self.dw_op(rec['dw'][i], f, sw))
-                sw = True
-            t = self.dw_op(rec['hdw'], f, True)
+        feats, sw = list(self.levels), False
+        for i in range(len(rec['dw'])):                      # layer-major: the five levels of a depthwise conv = one launch
+            ts = self.dw_multi_op(rec['dw'][i], feats, sw)
+            feats = self.pw_multi_op([rec['pw'][lvl][i] for lvl in range(len(ts))], ts)
+            sw = True
+        ts = self.dw_multi_op(rec['hdw'], feats, True)
+        # the header's pointwise conv (shared weight, no BN): the five levels = ONE launch each for the forward, the
+        # weight gradient (one workspace per level spec, mi355_conv_wgrad_multi) and the data gradient
+        grouped = self.prec != 'fp32' and self.deterministic and len(ts) <= ops_conv.MAX_PROBLEMS and \
+            os.environ.get('MI355_EFF_GROUP_HDR', '1') != '0'
+        fprobs, items = [], []
+        for lvl, t in enumerate(ts):
             spec = rec['hpw'][lvl]
             h, w = t.shape[1], t.shape[2]
             off = self.cell_off[lvl]
             pr = fwd_problem(t, out.data_ptr() + 4 * off * kout, 1, 1, 1, 0, out_strides=(per_img, w * kout, kout),
                              K=kout)
-            self._gather(self.fwd_steps, [pr], spec.w_fwd, kout, 1, bias=spec.conv.bias, act=act, out_f32=True)
+            fprobs.append(pr)
+            items.append((t, spec, h, w, off))
             self.fwd_launches.append((spec, [(B, h, w)]))
+        spec0 = rec['hpw'][0]
+        if grouped:
+            self._gather(self.fwd_steps, fprobs, spec0.w_fwd, kout, 1, bias=spec0.conv.bias, act=act, out_f32=True)
+        else:
+            for pr, (t, spec, h, w, off) in zip(fprobs, items):
+                self._gather(self.fwd_steps, [pr], spec.w_fwd, kout, 1, bias=spec.conv.bias, act=act, out_f32=True)
 
-            def bwd(t=t, spec=spec, h=h, w=w, off=off):
+        def bwd():
+            group, dprobs = [], []
+            for t, spec, h, w, off in items:
                 dy_ptr = gout.data_ptr() + self.esz * off * pitch
                 wp = fwd_problem(t, dy_ptr, 1, 1, 1, 0, K=pitch)
                 wp.out_sN = self.ncells * pitch
-                self._wgrad([wp], spec, B * h * w)
+                group.append((wp, spec, B * h * w))
                 gt = self.grad(t)
                 assert self.first_write(t)
                 dp = ConvProblem()
@@ -528,8 +662,15 @@ class EffDetPlan(RetinaPlan):
                 dp.out_mh, dp.out_oh, dp.out_mw, dp.out_ow = 1, 0, 1, 0
                 dp.out_sN, dp.out_sH, dp.out_sW = h * w * spec.Cpad, w * spec.Cpad, spec.Cpad
                 dp.in_sN = self.ncells * pitch
-                self._gather(self.bwd_steps, [dp], spec.w_dgr, spec.Cpad, 1)
-            self.tape.append(bwd)
+                dprobs.append(dp)
+            if grouped:
+                self._wgrad_multi(group)
+                self._gather(self.bwd_steps, dprobs, spec0.w_dgr, spec0.Cpad, 1)
+            else:
+                for (wp, spec, rows), dp in zip(group, dprobs):
+                    self._wgrad([wp], spec, rows)
+                    self._gather(self.bwd_steps, [dp], spec.w_dgr, spec.Cpad, 1)
+        self.tape.append(bwd)
 
     # ------------------------------------------------------------------ backward
     def _build_backward(self):
@@ -544,7 +685,8 @@ class EffDetPlan(RetinaPlan):
             return
         super(EffDetPlan, self)._step(lst, name, *args)
 
-    SIDE_STEPS = RetinaPlan.SIDE_STEPS + ('mi355_dwconv_wgrad', 'mi355_dwconv_wgrad_f32')
+    SIDE_STEPS = RetinaPlan.SIDE_STEPS + ('mi355_dwconv_wgrad', 'mi355_dwconv_wgrad_f32', 'mi355_dwconv_wgrad_slabs',
+                                          'mi355_dwconv_wgrad_slabs_multi')
 
     def _run(self, steps, stream):
         """As RetinaPlan._run (weight gradients on the side stream: they only read activations / output
@@ -563,17 +705,7 @@ class EffDetPlan(RetinaPlan):
                     raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, lib.mi355_last_error().decode()))
                 continue
             if fn is None:
-                if name == '__se_fc_bwd__':
-                    spec, pool, rpre, gate, ggate, gpool, N, slabs = self._se_bwd[args[0]]
-                    rc = lib.mi355_se_fc_bwd(ptr(pool), ptr(spec.reduce.weight), ptr(spec.expand.weight), ptr(rpre),
-                                             ptr(gate), ptr(ggate), c_int(slabs), ptr(gpool),
-                                             ptr(self.grad_view(spec.reduce.weight, arena)),
-                                             ptr(self.grad_view(spec.reduce.bias, arena)),
-                                             ptr(self.grad_view(spec.expand.weight, arena)),
-                                             ptr(self.grad_view(spec.expand.bias, arena)),
-                                             c_int(N), c_int(spec.C), c_int(spec.Cse), s)
-                else:
-                    raise _lib.Mi355Error('unknown deferred step %r' % (name,))
+                raise _lib.Mi355Error('unknown deferred step %r' % (name,))
             else:
                 rc = fn(*args, s)
             if rc:
@@ -587,7 +719,8 @@ class EffDetPlan(RetinaPlan):
         return flat.view(p.shape)
 
     def _zero_extra(self):
-        self.dw_scratch.zero_()
+        if getattr(self, '_dw_atomic', False):
+            self.dw_scratch.zero_()
         self._zb.zero_()
 
     def _extra_param_grads(self, arena, stream):
@@ -602,19 +735,38 @@ class EffDetPlan(RetinaPlan):
 
                 def dp(t):
                     return 0 if t is None else t.data_ptr()
+                if s.slabs is not None:                      # [nslabs][(T + 1) * C] rows: taps, then the dy column sums
+                    g_t, csum, nsl, stride = s.slabs.data_ptr(), s.slabs.data_ptr() + s.T * s.C * 4, s.nslabs, (s.T + 1) * s.C
+                else:
+                    g_t, csum, nsl, stride = dp(s.G_t), dp(s.colsum), 1, 0
                 rows.append(DwGradDesc(
-                    dp(s.G_t), dp(s.conv.weight), dp(s.scale), dp(s.colsum if bn is not None else None),
+                    g_t, dp(s.conv.weight), dp(s.scale), csum if bn is not None else 0,
                     dp(bn.running_mean if bn is not None else None), dp(bn.running_var if bn is not None else None),
                     dp(self.grad_view(s.conv.weight, arena)),
                     dp(self.grad_view(bn.weight, arena) if bn is not None else None),
                     dp(self.grad_view(bn.bias, arena) if bn is not None else None),
-                    float(bn.eps) if bn is not None else 0.0, s.C, s.k * s.k, 1))
+                    float(bn.eps) if bn is not None else 0.0, s.C, s.k * s.k, 1, nsl, stride))
             arr = (DwGradDesc * len(rows))(*rows)
             dev_tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.dev)
             tab = (dev_tab, len(rows), max(s.C for s in self.dw_specs))
             tabs[arena] = tab
         if tab[1]:
             _lib.call('mi355_dw_param_grads_table', ptr(tab[0]), c_int(tab[1]), c_int(tab[2]), c_vp(stream))
+        if self._se_bwd:
+            stabs = self.__dict__.setdefault('_se_pg_tables', {})
+            stab = stabs.get(arena)
+            if stab is None:
+                rows = [SeGradDesc(pool.data_ptr(), rpre.data_ptr(), de.data_ptr(), dr.data_ptr(),
+                                   self.grad_view(sp.reduce.weight, arena).data_ptr(),
+                                   self.grad_view(sp.reduce.bias, arena).data_ptr(),
+                                   self.grad_view(sp.expand.weight, arena).data_ptr(),
+                                   self.grad_view(sp.expand.bias, arena).data_ptr(), N, sp.C, sp.Cse, 0)
+                        for sp, pool, rpre, de, dr, N in self._se_bwd]
+                arr = (SeGradDesc * len(rows))(*rows)
+                dev_tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.dev)
+                stab = (dev_tab, len(rows), max(2 * sp.C * sp.Cse + sp.C + sp.Cse for sp, _, _, _, _, _ in self._se_bwd))
+                stabs[arena] = stab
+            _lib.call('mi355_se_param_grads_table', ptr(stab[0]), c_int(stab[1]), c_int(stab[2]), c_vp(stream))
         if self._fusion_bwd:
             ftabs = self.__dict__.setdefault('_fusion_bwd_tables', {})
             ftab = ftabs.get(arena)
@@ -627,6 +779,22 @@ class EffDetPlan(RetinaPlan):
             _lib.call('mi355_fusion_weights_bwd_table', ptr(ftab), c_int(len(self._fusion_bwd)), c_f32(1e-4),
                       c_vp(stream))
 
+    def draw_drop_connect(self):
+        """One uniform per (block, image) for this step's stochastic depth (efficientnet.py drop_connect), from a
+        plan-owned device generator seeded per data-parallel rank: replicas that all start from
+        torch.manual_seed(s) must not drop the same branches of their shards."""
+        if not (self.drop_connect and self._dc_rows):
+            return
+        if self.dc_inject is not None:
+            self.dc_u[:self.dc_inject.shape[0]].copy_(self.dc_inject)
+            return
+        if getattr(self, '_dc_gen', None) is None:
+            import torch.distributed as dist
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+            self._dc_gen = torch.Generator(device=self.dev)
+            self._dc_gen.manual_seed(torch.initial_seed() + 1000003 * rank)
+        self.dc_u.uniform_(generator=self._dc_gen)
+
     def run_heads(self, img):
         self._zf.zero_()
         if self._fusion_table is None and self._fusion_rows:
@@ -634,18 +802,8 @@ class EffDetPlan(RetinaPlan):
             self._fusion_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.dev)
             self._step(self.prep_steps, 'mi355_fusion_weights_table', ptr(self._fusion_table),
                        c_int(len(self._fusion_rows)), c_f32(1e-4))
-        if self.drop_connect and self._dc_rows:
-            if self.dc_inject is not None:
-                self.dc_u[:self.dc_inject.shape[0]].copy_(self.dc_inject)
-            else:
-                # one uniform per (block, image) from a plan-owned device generator seeded per data-parallel rank:
-                # replicas that all start from torch.manual_seed(s) must not drop the same branches of their shards
-                if getattr(self, '_dc_gen', None) is None:
-                    import torch.distributed as dist
-                    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
-                    self._dc_gen = torch.Generator(device=self.dev)
-                    self._dc_gen.manual_seed(torch.initial_seed() + 1000003 * rank)
-                self.dc_u.uniform_(generator=self._dc_gen)
+        if not torch.cuda.is_current_stream_capturing():
+            self.draw_drop_connect()               # graph replay: Trainer._step_graph draws before each replay
         super(EffDetPlan, self).run_heads(img)
 
     def _arena_for_backward(self):

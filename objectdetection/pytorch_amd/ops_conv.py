@@ -22,7 +22,8 @@ class ConvProblem(ctypes.Structure):
                 ('out_mh', c_int), ('out_oh', c_int), ('out_mw', c_int), ('out_ow', c_int),
                 ('out_sN', c_i64), ('out_sH', c_i64), ('out_sW', c_i64),
                 ('add_sN', c_i64), ('add_sH', c_i64), ('add_sW', c_i64),
-                ('add_shift', c_int), ('reserved', c_int), ('in_sN', c_i64)]
+                ('add_shift', c_int), ('reserved', c_int), ('in_sN', c_i64),
+                ('weight', c_vp), ('bias', c_vp)]       # optional per-problem weights / bias (bf16 gather launches)
 
 
 class ConvLaunch(ctypes.Structure):

@@ -243,6 +243,9 @@ class Trainer(object):
             self._graphs = (g1, g2)
             return first                           # this step already ran eagerly (the warm-up)
         g1, g2 = self._graphs
+        draw = getattr(self._g_plan, 'draw_drop_connect', None)
+        if draw is not None:
+            draw()                                 # stochastic-depth uniforms are drawn outside the captured region
         g1.replay()
         self._s_flag.copy_(self._exchange(self._g_plan, self._g_losses))
         g2.replay()

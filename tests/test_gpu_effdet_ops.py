@@ -64,6 +64,62 @@ def test_depthwise_conv(N, H, W, C, k, s, sw):
     # raw wgrad G (w.r.t. the scaled weight) = dL/dw / scale
     _close(dw_t.t().reshape(C, 1, k, k) * scale.to(DEV)[:, None, None, None], w.grad, 5e-3)
     _close(cs, gy.sum((0, 2, 3)), 2e-3)
+    # the LDS-tiled slab form: same sums, plain stores into NaN-filled rows (every element is written), and
+    # bit-reproducible launch to launch
+    sl = E.dwconv_wgrad_slabs(zh, sw, gyh, k, s)
+    assert torch.isfinite(sl).all()
+    tot = sl.double().sum(0).float()
+    _close(tot[:k * k * C].view(k * k, C).t().reshape(C, 1, k, k) * scale.to(DEV)[:, None, None, None], w.grad, 5e-3)
+    _close(tot[k * k * C:], gy.sum((0, 2, 3)), 2e-3)
+    assert torch.equal(sl, E.dwconv_wgrad_slabs(zh, sw, gyh, k, s))
+
+
+@pytest.mark.parametrize('k,sw', [(3, True), (5, False)])
+def test_depthwise_wgrad_of_a_shared_conv_over_pyramid_levels(k, sw):
+    """One launch for the five pyramid levels of a shared head conv (efficientdet.py:269-359) = the sum of the
+    per-level weight gradients."""
+    from objectdetection.pytorch_amd import ops_effdet as E
+    C, N = 64, 2
+    pairs, ref_w, ref_cs = [], 0.0, 0.0
+    for i, hw in enumerate((40, 20, 10, 5, 3)):
+        z = _mk((N, C, hw, hw + (i % 2)), 10 + i)
+        gy = _mk((N, C, hw, hw + (i % 2)), 20 + i)
+        zh, gyh = _nhwc(z), _nhwc(gy)
+        pairs.append((zh, gyh))
+        one = E.dwconv_wgrad_slabs(zh, sw, gyh, k, 1).double().sum(0)
+        ref_w, ref_cs = ref_w + one[:k * k * C], ref_cs + one[k * k * C:]
+    sl = E.dwconv_wgrad_slabs_multi(pairs, sw, k, 1)
+    assert torch.isfinite(sl).all()
+    tot = sl.double().sum(0)
+    _close(tot[:k * k * C].float(), ref_w.float().cpu(), 1e-5)
+    _close(tot[k * k * C:].float(), ref_cs.float().cpu(), 1e-5)
+    assert torch.equal(sl, E.dwconv_wgrad_slabs_multi(pairs, sw, k, 1))
+
+
+@pytest.mark.parametrize('k,sw', [(3, True), (5, False)])
+def test_depthwise_fwd_and_dgrad_over_pyramid_levels_in_one_launch(k, sw):
+    """mi355_dwconv_fwd_multi / _dgrad_multi == the per-map launches, bit for bit (same kernel, level table)."""
+    from objectdetection.pytorch_amd import ops_effdet as E
+    C, N = 64, 2
+    w_t = (torch.randn((k * k, C), generator=torch.Generator().manual_seed(1)) * 0.3).to(DEV)
+    bias = (torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.1).to(DEV)
+    xs = [_nhwc(_mk((N, C, hw, hw + (i % 2)), 30 + i)) for i, hw in enumerate((40, 20, 10, 5, 3))]
+    outs = E.dwconv_fwd_multi(xs, sw, w_t, bias, k)
+    for x, o in zip(xs, outs):
+        one = E.dwconv_fwd(x, sw, w_t, bias, k, 1)
+        if x.shape[2] >= 16 and x.shape[1] >= 8:          # the single-map entry takes the tile kernel there
+            assert torch.equal(o, one)
+        else:
+            _close(o, one.float().cpu(), 1e-2)
+    dys = [_nhwc(_mk((N, C, x.shape[1], x.shape[2]), 50 + i)) for i, x in enumerate(xs)]
+    base = [torch.randn_like(d.float()).to(torch.bfloat16) for d in dys]
+    dxs = E.dwconv_dgrad_multi(dys, w_t, k, zins=xs if sw else None, dxs=[b.clone() for b in base], accumulate=True)
+    for x, dy, b, dx in zip(xs, dys, base, dxs):
+        one = E.dwconv_dgrad(dy, w_t, tuple(x.shape), k, 1, zin=x if sw else None, dx=b.clone(), accumulate=True)
+        if x.shape[2] >= 16 and x.shape[1] >= 8:
+            assert torch.equal(dx, one)
+        else:
+            _close(dx, one.float().cpu(), 2e-2)
 
 
 def test_maxpool_same_zero_padding():
@@ -125,6 +181,27 @@ def test_squeeze_excite_fwd_bwd():
     _close(gz.permute(0, 3, 1, 2), z.grad, 1.5e-2)
     for got, ref in ((dW1, w1.grad), (dB1, b1.grad), (dW2, w2.grad), (dB2, b2.grad)):
         _close(got.reshape(ref.shape), ref, 5e-3)
+    # the atomic-free form: per-sample data path + one table launch for the parameter gradients (plain stores
+    # into NaN-filled buffers), bit-reproducible
+    from objectdetection.pytorch_amd.engine_effdet import SeGradDesc
+
+    def run():
+        de = torch.full((N, C), float('nan'), device=dev)
+        dr = torch.full((N, Cse), float('nan'), device=dev)
+        gp = torch.full((N, C), float('nan'), device=dev)
+        call('mi355_se_fc_bwd_data', ptr(W1), ptr(W2), ptr(rpre), ptr(g), ptr(ggate), c_int(slabs), ptr(de), ptr(dr),
+             ptr(gp), c_int(N), c_int(C), c_int(Cse), stream_of(zh))
+        outs = [torch.full_like(t, float('nan')) for t in (W1, B1, W2, B2)]
+        row = SeGradDesc(pool.data_ptr(), rpre.data_ptr(), de.data_ptr(), dr.data_ptr(), outs[0].data_ptr(),
+                         outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr(), N, C, Cse, 0)
+        tab = torch.frombuffer(bytearray(bytes(row)), dtype=torch.uint8).clone().to(dev)
+        call('mi355_se_param_grads_table', ptr(tab), c_int(1), c_int(2 * C * Cse + C + Cse), stream_of(zh))
+        return [gp] + outs
+    a1, a2 = run(), run()
+    _close(a1[0], gpool.cpu(), 1e-5)
+    for got, ref in zip(a1[1:], (w1.grad, b1.grad, w2.grad, b2.grad)):
+        _close(got.reshape(ref.shape), ref, 5e-3)
+    assert all(torch.equal(x, y) for x, y in zip(a1, a2))
 
 
 def test_bifpn_node_and_fusion_weights():
