@@ -151,6 +151,15 @@ int mi355_axpy_bf16(const void* src, const float* w, int wi, void* dst, int64_t 
  * per_image = H*W*C elements.  Backward of the branch = the same call on the gradient with addend NULL. */
 int mi355_drop_connect(const void* src, const float* u, float keep, const void* addend, void* dst, int N,
                        int64_t per_image, void* stream);
+/* The whole backward of a node in one pass: g_i = w[i] * gz (+ g_i when acc_i) for in0, in1 (2x2 sums of gz when up1:
+ * g1 is [N][H/2][W/2][C]) and in2 (may be NULL), and gw[i] += <gz, in_i> when gw is non-NULL (efficientdet.py:213-265
+ * as autograd differentiates it). */
+int mi355_bifpn_node_bwd(const void* gz, const void* in0, const void* in1, int up1, const void* in2, const float* w,
+                         float* gw, void* g0, int acc0, void* g1, int acc1, void* g2, int acc2, int N, int H, int W, int C,
+                         void* stream);
+int mi355_bifpn_node_bwd_f32(const void* gz, const void* in0, const void* in1, int up1, const void* in2, const float* w,
+                             float* gw, void* g0, int acc0, void* g1, int acc1, void* g2, int acc2, int N, int H, int W,
+                             int C, void* stream);
 /* dst[N][H/2][W/2][C] (+)= w[wi] * (sum of the 2x2 children of src[N][H][W][C]) */
 int mi355_upsample_bwd_axpy(const void* src, const float* w, int wi, void* dst, int N, int H, int W, int C,
                             int accumulate, void* stream);

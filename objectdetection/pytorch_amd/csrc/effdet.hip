@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pa
                                                     const float* __restrict__ b1, const float* __restrict__ w2,
                                                     const float* __restrict__ b2, float* __restrict__ rpre,
                                                     float* __restrict__ gate, int C, int Cse) {
-    extern __shared__ float sm[];                  // pool[C] | r[Cse]
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // pool[C] | r[Cse]
     float* s_pool = sm;
     float* s_r = sm + C;
     const int n = blockIdx.x, tid = threadIdx.x;
@@ -1324,11 +1324,13 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pa
     const int wave = tid >> 6, lane = tid & 63;
     for (int j0 = wave * 4; j0 < Cse; j0 += 16) {
         float t[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        // (rows past Cse re-read the last row and are dropped: no branch around the loads, so that the unrolled loop
+        //  keeps 16 of them in flight; parameters live in a flat arena at 4-B granularity: scalar loads)
+#pragma unroll 4
         for (int c = lane; c < C; c += 64) {
             const float pv = s_pool[c];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (j0 + u < Cse) t[u] += w1[(j0 + u) * C + c] * pv;
+            for (int u = 0; u < 4; ++u) t[u] += w1[(long long)min(j0 + u, Cse - 1) * C + c] * pv;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1719,6 +1721,111 @@ extern "C" int mi355_bifpn_node_wgrad(const void* gz, const void* in0, const voi
                        (const unsigned short*)gz, (const unsigned short*)in0, (const unsigned short*)in1, up1,
                        (const unsigned short*)in2, nullptr, nullptr, gw, N, H, W, C);
     return check_launch("bifpn_node_kernel<wgrad>");
+}
+
+// The whole backward of a BiFPN node in one pass over gz (a node's backward was its fusion-weight reduction plus one
+// axpy launch per input: 4-5 launches of 3-8 us for 2-3 MB of tensors): g_i (+)= w_i * gz for the three inputs (the
+// half-resolution input of a top-down node takes the sum of its 2 x 2 gz pixels: a thread owns one such quad, so
+// nothing is added across threads) and gw_i += <gz, in_i> (block sums, one atomic per block and weight).
+template <typename T>
+__global__ __launch_bounds__(256) void bifpn_node_bwd_kernel(const T* __restrict__ gz, const T* __restrict__ in0,
+                                                             const T* __restrict__ in1, int up1,
+                                                             const T* __restrict__ in2, const float* __restrict__ w,
+                                                             float* __restrict__ gw, T* __restrict__ g0, int acc0,
+                                                             T* __restrict__ g1, int acc1, T* __restrict__ g2, int acc2,
+                                                             int N, int H, int W, int C) {
+    const int c8n = C >> 3;
+    const int step = up1 ? 2 : 1, Hq = H / step, Wq = W / step;
+    const long long total = (long long)N * Hq * Wq * c8n;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (t < total) {
+        const int c8 = (int)(t % c8n);
+        long long r = t / c8n;
+        const int xq = (int)(r % Wq);  r /= Wq;
+        const int yq = (int)(r % Hq);
+        const int n = (int)(r / Hq);
+        const float w0 = w[0], w1 = w[1], w2 = w[2];
+        float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int dy = 0; dy < step; ++dy)
+            for (int dx = 0; dx < step; ++dx) {
+                const long long o = ((((long long)n * H + yq * step + dy) * W + xq * step + dx) * c8n + c8) * 8;
+                float g[8], a[8], v[8];
+                load8(gz + o, g);
+                load8(in0 + o, a);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { d0 += g[e] * a[e]; sum[e] += g[e]; v[e] = w0 * g[e]; }
+                if (acc0) {
+                    float old[8];
+                    load8(g0 + o, old);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += old[e];
+                }
+                store8(g0 + o, v);
+                if (in2) {
+                    float c[8];
+                    load8(in2 + o, c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { d2 += g[e] * c[e]; v[e] = w2 * g[e]; }
+                    if (acc2) {
+                        float old[8];
+                        load8(g2 + o, old);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += old[e];
+                    }
+                    store8(g2 + o, v);
+                }
+            }
+        const long long o1 = t * 8;                       // in1 / g1: [N][Hq][Wq][C]
+        float b[8], v[8];
+        load8(in1 + o1, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { d1 += sum[e] * b[e]; v[e] = w1 * sum[e]; }
+        if (acc1) {
+            float old[8];
+            load8(g1 + o1, old);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += old[e];
+        }
+        store8(g1 + o1, v);
+    }
+    if (gw) {
+        __shared__ float red[3][4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            d0 += __shfl_down(d0, o, 64); d1 += __shfl_down(d1, o, 64); d2 += __shfl_down(d2, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d0; red[1][threadIdx.x >> 6] = d1; red[2][threadIdx.x >> 6] = d2; }
+        __syncthreads();
+        if (threadIdx.x < 3) atomicAdd(gw + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
+}
+
+template <typename T>
+static int launch_bifpn_node_bwd(const void* gz, const void* in0, const void* in1, int up1, const void* in2, const float* w,
+                                 float* gw, void* g0, int acc0, void* g1, int acc1, void* g2, int acc2, int N, int H, int W,
+                                 int C, void* stream) {
+    MI355_REQUIRE(gz && in0 && in1 && w && g0 && g1 && (!in2 || g2) && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0,
+                  "bifpn_node_bwd: bad args");
+    MI355_REQUIRE(!up1 || (H % 2 == 0 && W % 2 == 0), "bifpn_node_bwd: upsample needs even H, W");
+    const int step = up1 ? 2 : 1;
+    const long long total = (long long)N * (H / step) * (W / step) * (C / 8);
+    hipLaunchKernelGGL(bifpn_node_bwd_kernel<T>, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const T*)gz,
+                       (const T*)in0, (const T*)in1, up1, (const T*)in2, w, gw, (T*)g0, acc0, (T*)g1, acc1, (T*)g2, acc2,
+                       N, H, W, C);
+    return check_launch("bifpn_node_bwd_kernel");
+}
+
+extern "C" int mi355_bifpn_node_bwd(const void* gz, const void* in0, const void* in1, int up1, const void* in2,
+                                    const float* w, float* gw, void* g0, int acc0, void* g1, int acc1, void* g2, int acc2,
+                                    int N, int H, int W, int C, void* stream) {
+    return launch_bifpn_node_bwd<unsigned short>(gz, in0, in1, up1, in2, w, gw, g0, acc0, g1, acc1, g2, acc2, N, H, W, C, stream);
+}
+
+extern "C" int mi355_bifpn_node_bwd_f32(const void* gz, const void* in0, const void* in1, int up1, const void* in2,
+                                        const float* w, float* gw, void* g0, int acc0, void* g1, int acc1, void* g2,
+                                        int acc2, int N, int H, int W, int C, void* stream) {
+    return launch_bifpn_node_bwd<float>(gz, in0, in1, up1, in2, w, gw, g0, acc0, g1, acc1, g2, acc2, N, H, W, C, stream);
 }
 
 template <typename T>

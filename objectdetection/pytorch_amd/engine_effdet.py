@@ -429,19 +429,16 @@ class EffDetPlan(RetinaPlan):
             if not self.has_grad(z):
                 return
             gz = self.grad(z)
+            gw = None
             if param is not None:
                 gw = self._zero_bwd_alloc(4)
-                self._step(self.bwd_steps, 'mi355_bifpn_node_wgrad', ptr(gz), ptr(in0), ptr(in1), c_int(int(up1)),
-                           ptr(in2), ptr(gw), *dims)
                 self._fusion_bwd.append((param, n, gw))      # all nodes: one table launch behind the backward list
-            self._axpy(gz, w, 0, self.grad(in0), not self.first_write(in0))
-            if up1:
-                self._step(self.bwd_steps, 'mi355_upsample_bwd_axpy', ptr(gz), ptr(w), c_int(1), ptr(self.grad(in1)),
-                           *(dims + (c_int(int(not self.first_write(in1))),)))
-            else:
-                self._axpy(gz, w, 1, self.grad(in1), not self.first_write(in1))
-            if in2 is not None:
-                self._axpy(gz, w, 2, self.grad(in2), not self.first_write(in2))
+            # the three input gradients and the fusion-weight sums in ONE pass over gz
+            g0, a0 = self.grad(in0), not self.first_write(in0)
+            g1, a1 = self.grad(in1), not self.first_write(in1)
+            g2, a2 = (self.grad(in2), not self.first_write(in2)) if in2 is not None else (None, False)
+            self._step(self.bwd_steps, 'mi355_bifpn_node_bwd', ptr(gz), ptr(in0), ptr(in1), c_int(int(up1)), ptr(in2),
+                       ptr(w), ptr(gw), ptr(g0), c_int(int(a0)), ptr(g1), c_int(int(a1)), ptr(g2), c_int(int(a2)), *dims)
         self.tape.append(bwd)
         return z
 

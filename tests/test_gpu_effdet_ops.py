@@ -204,6 +204,34 @@ def test_squeeze_excite_fwd_bwd():
     assert all(torch.equal(x, y) for x, y in zip(a1, a2))
 
 
+@pytest.mark.parametrize('up1,three', [(True, True), (True, False), (False, True)])
+def test_bifpn_node_backward_in_one_pass(up1, three):
+    """mi355_bifpn_node_bwd == fusion-weight sums + one scaled accumulate per input (efficientdet.py:213-265)."""
+    from objectdetection.pytorch_amd._lib import call, ptr, c_int, stream_of
+    N, C, H, W = 2, 64, 8, 12
+    wv = torch.tensor([0.31, 0.52, 0.17 if three else 0.0])
+    a = _mk((N, C, H, W), 1).requires_grad_(True)
+    b = _mk((N, C, H // 2, W // 2) if up1 else (N, C, H, W), 2).requires_grad_(True)
+    c = _mk((N, C, H, W), 3).requires_grad_(True)
+    wp = wv.clone().requires_grad_(True)
+    z = wp[0] * a + wp[1] * (F.interpolate(b, scale_factor=2, mode='nearest') if up1 else b)
+    if three:
+        z = z + wp[2] * c
+    gz = _mk(tuple(z.shape), 4)
+    z.backward(gz)
+    ah, bh, ch, gh = _nhwc(a.detach()), _nhwc(b.detach()), _nhwc(c.detach()), _nhwc(gz)
+    old = [_nhwc(_mk(tuple(t.shape), 10 + i)) for i, t in enumerate((a, b, c))]
+    for acc in (0, 1):
+        g = [o.clone() for o in old]
+        gw = torch.zeros(4, device=DEV)
+        call('mi355_bifpn_node_bwd', ptr(gh), ptr(ah), ptr(bh), c_int(int(up1)), ptr(ch if three else None),
+             ptr(wv.to(DEV)), ptr(gw), ptr(g[0]), c_int(acc), ptr(g[1]), c_int(acc), ptr(g[2] if three else None),
+             c_int(acc), c_int(N), c_int(H), c_int(W), c_int(C), stream_of(ah))
+        _close(gw[:3], wp.grad, 5e-3)
+        for got, o, ref in zip(g if three else g[:2], old, (a.grad, b.grad, c.grad)):
+            _close(got.permute(0, 3, 1, 2), ref + (o.float().cpu().permute(0, 3, 1, 2) if acc else 0.0), 1e-2)
+
+
 def test_bifpn_node_and_fusion_weights():
     from objectdetection.pytorch_amd._lib import call, ptr, c_int, c_f32, c_i64, stream_of
     N, C, H, W = 2, 64, 8, 12
