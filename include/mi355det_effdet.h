@@ -151,6 +151,12 @@ int mi355_axpy_bf16(const void* src, const float* w, int wi, void* dst, int64_t 
  * per_image = H*W*C elements.  Backward of the branch = the same call on the gradient with addend NULL. */
 int mi355_drop_connect(const void* src, const float* u, float keep, const void* addend, void* dst, int N,
                        int64_t per_image, void* stream);
+/* mi355_bifpn_node_fwd + mi355_dwconv_fwd(in_swish = 1, stride 1, "same") in ONE launch: z (stored: the backward
+ * reads it) is built while the depthwise conv's halo tile is staged; bit-identical to the two launches.
+ * (efficientdet.py:213-265: `self.conv6_up(self.swish(weight[0] * p6_in + weight[1] * self.p6_upsample(p7_in)))` ...) */
+int mi355_bifpn_node_dwconv_fwd(const void* in0, const void* in1, int up1, const void* in2, const float* w, void* z,
+                                const float* w_t, const float* bias, void* out, int N, int H, int W, int C, int k,
+                                void* stream);
 /* The whole backward of a node in one pass: g_i = w[i] * gz (+ g_i when acc_i) for in0, in1 (2x2 sums of gz when up1:
  * g1 is [N][H/2][W/2][C]) and in2 (may be NULL), and gw[i] += <gz, in_i> when gw is non-NULL (efficientdet.py:213-265
  * as autograd differentiates it). */

@@ -60,6 +60,10 @@ template <> struct Act<float> {
     static __device__ __forceinline__ float dsw(float x) { return dswishf_exact(x); }
 };
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+// BiFPN fast-attention mix, one explicit fma chain wherever a node is evaluated (bit-identical z in every kernel)
+__device__ __forceinline__ float node_mix(float w0, float a, float w1, float b, float w2, float c) {
+    return fmaf(w2, c, fmaf(w1, b, w0 * a));
+}
 
 }  // namespace
 
@@ -207,8 +211,16 @@ struct DwTileLevel {
 struct DwTileLaunch {
     DwTileLevel lv[MI355_DW_MAX_LEVELS];
     int nlevels, C, nc8, pad_t, pad_l, accumulate;
+    // NODE form (one level): the conv's input is the BiFPN fast-attention node z = w[0] in + w[1] in1' + w[2] in2
+    // (efficientdet.py:213-265), built while the halo tile is staged and stored to `zout` by the tile that owns the
+    // pixel (the backward reads z); in1' = nearest-2x upsample of in1 [N][H/2][W/2][C] when up1
+    const unsigned short* in1;
+    const unsigned short* in2;
+    unsigned short* zout;
+    const float* nodew;
+    int up1;
 };
-template <int K, bool FLIP, bool INSW = false>
+template <int K, bool FLIP, bool INSW = false, bool NODE = false>
 __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, const float* __restrict__ w_t,
                                                          const float* __restrict__ bias) {
     constexpr int IH = DT_TH + K - 1, IW = DT_TW + K - 1, NPX = IH * IW;
@@ -237,8 +249,23 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, c
         const int iy = px / IW, ix = px - iy * IW;
         const int h = p0 - pad_t + iy, w = q0 - pad_l + ix;
         s8v v = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
-        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W)
-            v = *reinterpret_cast<const s8v*>(in + (((long long)n * H + h) * W + w) * C + (c8b + ch) * 8);
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+            const long long o = (((long long)n * H + h) * W + w) * C + (c8b + ch) * 8;
+            v = *reinterpret_cast<const s8v*>(in + o);
+            if (NODE) {
+                const long long o1 = L.up1 ? ((((long long)n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * C + (c8b + ch) * 8) : o;
+                const s8v b = *reinterpret_cast<const s8v*>(L.in1 + o1);
+                s8v c = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+                if (L.in2) c = *reinterpret_cast<const s8v*>(L.in2 + o);
+                const float w0 = L.nodew[0], w1 = L.nodew[1], w2 = L.nodew[2];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)                // (same expression as bifpn_node_kernel: bit-identical z)
+                    v[e] = (short)f32_to_bf16_rn(node_mix(w0, bf16_to_f32((unsigned short)v[e]), w1, bf16_to_f32((unsigned short)b[e]),
+                                                          w2, bf16_to_f32((unsigned short)c[e])));
+                if (iy >= pad_t && iy < pad_t + DT_TH && ix >= pad_l && ix < pad_l + DT_TW)
+                    *reinterpret_cast<s8v*>(L.zout + o) = v;   // this tile's own output pixels
+            }
+        }
         if (INSW) {                                        // input stored as pre-activation z: swish once per loaded
 #pragma unroll                                             // element, rounded to bf16 like a materialised swish(z)
             for (int e = 0; e < 8; ++e) v[e] = (short)f32_to_bf16_rn(swishf(bf16_to_f32((unsigned short)v[e])));
@@ -315,12 +342,18 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, c
 
 // levels[i]: x = the map the conv reads (forward: input; data gradient: dy), dy = the map it writes (forward:
 // output; data gradient: dx), aux = zin (data gradient only)
-template <int K, bool FLIP, bool INSW = false>
+struct DwNodeArgs { const void* in1; const void* in2; void* zout; const float* w; int up1; };
+
+template <int K, bool FLIP, bool INSW = false, bool NODE = false>
 static int launch_dw_tile(const Mi355DwLevel* levels, int nlevels, const float* w_t, const float* bias, int accumulate,
-                          int N, int C, int pad_t, int pad_l, void* stream) {
+                          int N, int C, int pad_t, int pad_l, void* stream, const DwNodeArgs* node = nullptr) {
     const int c8n = C / 8;
     DwTileLaunch L;
     memset(&L, 0, sizeof(L));
+    if (NODE) {
+        L.in1 = (const unsigned short*)node->in1;  L.in2 = (const unsigned short*)node->in2;
+        L.zout = (unsigned short*)node->zout;  L.nodew = node->w;  L.up1 = node->up1;
+    }
     L.nlevels = nlevels; L.C = C; L.pad_t = pad_t; L.pad_l = pad_l; L.accumulate = accumulate;
     L.nc8 = c8n % 4 == 0 ? 4 : (c8n % 2 == 0 ? 2 : 1);
     long long tiles = 0;
@@ -340,11 +373,28 @@ static int launch_dw_tile(const Mi355DwLevel* levels, int nlevels, const float* 
     const dim3 grid((unsigned)tiles, (unsigned)(N * (c8n / L.nc8)));
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)dw_tile_s1_kernel<K, FLIP, INSW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)dw_tile_s1_kernel<K, FLIP, INSW, NODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((dw_tile_s1_kernel<K, FLIP, INSW>), grid, dim3(256), lds, (hipStream_t)stream, L, w_t, bias);
+    hipLaunchKernelGGL((dw_tile_s1_kernel<K, FLIP, INSW, NODE>), grid, dim3(256), lds, (hipStream_t)stream, L, w_t, bias);
     return check_launch("dw_tile_s1_kernel");
+}
+
+// z = w[0] in0 + w[1] in1' + w[2] in2 (stored), out = dwconv_kxk(swish(z)) + bias: mi355_bifpn_node_fwd followed by
+// mi355_dwconv_fwd(in_swish = 1) in one launch, bit-identical to the pair
+extern "C" int mi355_bifpn_node_dwconv_fwd(const void* in0, const void* in1, int up1, const void* in2, const float* w,
+                                           void* z, const float* w_t, const float* bias, void* out, int N, int H, int W,
+                                           int C, int k, void* stream) {
+    MI355_REQUIRE(in0 && in1 && w && z && w_t && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && (k == 3 || k == 5),
+                  "bifpn_node_dwconv_fwd: bad args (k = 3 or 5)");
+    MI355_REQUIRE(!up1 || (H % 2 == 0 && W % 2 == 0), "bifpn_node_dwconv_fwd: upsample needs even H, W");
+    Mi355DwLevel lv;
+    memset(&lv, 0, sizeof(lv));
+    lv.x = in0; lv.dy = out; lv.H = H; lv.W = W;
+    const DwNodeArgs node = {in1, in2, z, w, up1};
+    const int p = (k - 1) / 2;
+    return k == 3 ? launch_dw_tile<3, false, true, true>(&lv, 1, w_t, bias, 0, N, C, p, p, stream, &node)
+                  : launch_dw_tile<5, false, true, true>(&lv, 1, w_t, bias, 0, N, C, p, p, stream, &node);
 }
 
 static bool dw_levels_same_s1(const Mi355DwLevel* lv, int n, int k) {
@@ -1686,7 +1736,7 @@ __global__ __launch_bounds__(256) void bifpn_node_kernel(const T* __restrict__ g
             const float w0 = w[0], w1 = w[1], w2 = w[2];
             float o[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = w0 * a[e] + w1 * b[e] + w2 * c[e];
+            for (int e = 0; e < 8; ++e) o[e] = node_mix(w0, a[e], w1, b[e], w2, c[e]);
             store8(z + t * 8, o);
         }
     }

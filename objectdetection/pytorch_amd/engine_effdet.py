@@ -217,7 +217,9 @@ class EffDetPlan(RetinaPlan):
         self.tape.append(bwd)
         return out
 
-    def dw_op(self, spec, x, x_swish):
+    def dw_op(self, spec, x, x_swish, emit_fwd=True):
+        """(emit_fwd=False: the caller launches the forward itself, fused with the producer of x; everything else —
+        output buffer, slab rows, taped backward — is registered here.)"""
         N, H, W, C = x.shape
         pt, P = same_pad(H, spec.k, spec.stride)
         pl, Q = same_pad(W, spec.k, spec.stride)
@@ -228,8 +230,9 @@ class EffDetPlan(RetinaPlan):
         # LDS-tiled forward, once per kernel row in the sliding-window weight gradient; v_exp + v_rcp, rounded to
         # bf16 exactly like a materialised swish(z)): no elementwise pass, no second copy of the activation
         xs, insw = x, int(bool(x_swish))
-        self._step(self.fwd_steps, 'mi355_dwconv_fwd', ptr(xs), c_int(insw), ptr(spec.w_t), ptr(spec.shift),
-                   ptr(out), *geo)
+        if emit_fwd:
+            self._step(self.fwd_steps, 'mi355_dwconv_fwd', ptr(xs), c_int(insw), ptr(spec.w_t), ptr(spec.shift),
+                       ptr(out), *geo)
 
         # bf16 plans: bit-reproducible weight gradient, every launch of the layer (the pyramid levels of a shared head
         # conv) stores its own partial rows of the layer's slab workspace; fp32 plans: the generic atomic kernel
@@ -408,7 +411,21 @@ class EffDetPlan(RetinaPlan):
         self.tape.append(bwd)
         return out
 
-    def node_op(self, param, in0, in1, up1, in2=None):
+    def node_sep_op(self, pair, param, in0, in1, up1, in2=None):
+        """SeparableConvBlock(swish(node)): the node's weighted sum is built inside the depthwise conv's forward launch
+        (mi355_bifpn_node_dwconv_fwd: one launch and one pass over z fewer per node); backward as the two ops."""
+        dws, pws = pair
+        if self.prec == 'fp32' or dws.k not in (3, 5) or dws.stride != 1 or os.environ.get('MI355_EFF_FUSE_NODE', '1') == '0':
+            return self.sep_op(pair, self.node_op(param, in0, in1, up1, in2))
+        z = self.node_op(param, in0, in1, up1, in2, emit_fwd=False)
+        w = self._last_node_w
+        t = self.dw_op(dws, z, True, emit_fwd=False)
+        N, H, W, C = in0.shape
+        self._step(self.fwd_steps, 'mi355_bifpn_node_dwconv_fwd', ptr(in0), ptr(in1), c_int(int(up1)), ptr(in2), ptr(w),
+                   ptr(z), ptr(dws.w_t), ptr(dws.shift), ptr(t), c_int(N), c_int(H), c_int(W), c_int(C), c_int(dws.k))
+        return self.pw_op(pws, t)
+
+    def node_op(self, param, in0, in1, up1, in2=None, emit_fwd=True):
         """z = w0*in0 + w1*in1' (+ w2*in2), w = relu(p)/(sum relu(p) + 1e-4) (efficientdet.py:213-265)."""
         if param is None:
             # plain sum of the inputs (`_forward`, efficientdet.py:269-317: D6 / D7): unit weights, no parameter
@@ -422,8 +439,10 @@ class EffDetPlan(RetinaPlan):
         N, H, W, C = in0.shape
         z = self.new(tuple(in0.shape))
         dims = (c_int(N), c_int(H), c_int(W), c_int(C))
-        self._step(self.fwd_steps, 'mi355_bifpn_node_fwd', ptr(in0), ptr(in1), c_int(int(up1)), ptr(in2), ptr(w),
-                   ptr(z), *dims)
+        self._last_node_w = w
+        if emit_fwd:
+            self._step(self.fwd_steps, 'mi355_bifpn_node_fwd', ptr(in0), ptr(in1), c_int(int(up1)), ptr(in2), ptr(w),
+                       ptr(z), *dims)
 
         def bwd():
             if not self.has_grad(z):
@@ -597,17 +616,17 @@ class EffDetPlan(RetinaPlan):
             for n in ('p6_w1', 'p5_w1', 'p4_w1', 'p3_w1', 'p4_w2', 'p5_w2', 'p6_w2', 'p7_w2'):
                 if hasattr(cell, n):
                     self.unused_param_ids.add(id(getattr(cell, n)))
-        p6_up = self.sep_op(rec['conv6_up'], self.node_op(fw('p6_w1'), p6_in, p7_in, True))
-        p5_up = self.sep_op(rec['conv5_up'], self.node_op(fw('p5_w1'), p5_in, p6_up, True))
-        p4_up = self.sep_op(rec['conv4_up'], self.node_op(fw('p4_w1'), p4_in, p5_up, True))
-        p3_out = self.sep_op(rec['conv3_up'], self.node_op(fw('p3_w1'), p3_in, p4_up, True))
+        p6_up = self.node_sep_op(rec['conv6_up'], fw('p6_w1'), p6_in, p7_in, True)
+        p5_up = self.node_sep_op(rec['conv5_up'], fw('p5_w1'), p5_in, p6_up, True)
+        p4_up = self.node_sep_op(rec['conv4_up'], fw('p4_w1'), p4_in, p5_up, True)
+        p3_out = self.node_sep_op(rec['conv3_up'], fw('p3_w1'), p3_in, p4_up, True)
         if rec['first']:
             p4_in = self.pw_op(rec['p4_down_channel_2'], inputs[1])
             p5_in = self.pw_op(rec['p5_down_channel_2'], inputs[2])
-        p4_out = self.sep_op(rec['conv4_down'], self.node_op(fw('p4_w2'), p4_in, p4_up, False, self.pool_op(p3_out)))
-        p5_out = self.sep_op(rec['conv5_down'], self.node_op(fw('p5_w2'), p5_in, p5_up, False, self.pool_op(p4_out)))
-        p6_out = self.sep_op(rec['conv6_down'], self.node_op(fw('p6_w2'), p6_in, p6_up, False, self.pool_op(p5_out)))
-        p7_out = self.sep_op(rec['conv7_down'], self.node_op(fw('p7_w2'), p7_in, self.pool_op(p6_out), False))
+        p4_out = self.node_sep_op(rec['conv4_down'], fw('p4_w2'), p4_in, p4_up, False, self.pool_op(p3_out))
+        p5_out = self.node_sep_op(rec['conv5_down'], fw('p5_w2'), p5_in, p5_up, False, self.pool_op(p4_out))
+        p6_out = self.node_sep_op(rec['conv6_down'], fw('p6_w2'), p6_in, p6_up, False, self.pool_op(p5_out))
+        p7_out = self.node_sep_op(rec['conv7_down'], fw('p7_w2'), p7_in, self.pool_op(p6_out), False)
         return p3_out, p4_out, p5_out, p6_out, p7_out
 
     def _head_fwd(self, rec, out, kout, act, gout, pitch):

@@ -204,6 +204,30 @@ def test_squeeze_excite_fwd_bwd():
     assert all(torch.equal(x, y) for x, y in zip(a1, a2))
 
 
+@pytest.mark.parametrize('up1,three,hw', [(True, False, (16, 40)), (False, True, (10, 6)), (True, True, (4, 4))])
+def test_bifpn_node_built_inside_the_depthwise_forward(up1, three, hw):
+    """mi355_bifpn_node_dwconv_fwd == mi355_bifpn_node_fwd then the depthwise conv of swish(z), z included."""
+    from objectdetection.pytorch_amd import ops_effdet as E
+    from objectdetection.pytorch_amd._lib import call, ptr, c_int, stream_of
+    N, C, (H, W), k = 2, 64, hw, 3
+    wv = torch.tensor([0.31, 0.52, 0.17 if three else 0.0, 0.0], device=DEV)
+    a = _nhwc(_mk((N, C, H, W), 1))
+    b = _nhwc(_mk((N, C, H // 2, W // 2) if up1 else (N, C, H, W), 2))
+    c = _nhwc(_mk((N, C, H, W), 3)) if three else None
+    w_t = (torch.randn((k * k, C), generator=torch.Generator().manual_seed(1)) * 0.3).to(DEV)
+    bias = (torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.1).to(DEV)
+    z_ref = torch.empty_like(a)
+    call('mi355_bifpn_node_fwd', ptr(a), ptr(b), c_int(int(up1)), ptr(c), ptr(wv), ptr(z_ref), c_int(N), c_int(H), c_int(W),
+         c_int(C), stream_of(a))
+    t_ref = E.dwconv_fwd_multi([z_ref, z_ref], True, w_t, bias, k)[0]          # (the tile kernel at every size)
+    z = torch.full_like(a, float('nan'))
+    t = torch.full_like(a, float('nan'))
+    call('mi355_bifpn_node_dwconv_fwd', ptr(a), ptr(b), c_int(int(up1)), ptr(c), ptr(wv), ptr(z), ptr(w_t), ptr(bias), ptr(t),
+         c_int(N), c_int(H), c_int(W), c_int(C), c_int(k), stream_of(a))
+    assert torch.equal(z, z_ref), (z.float() - z_ref.float()).abs().max().item()
+    assert torch.equal(t, t_ref), (t.float() - t_ref.float()).abs().max().item()
+
+
 @pytest.mark.parametrize('up1,three', [(True, True), (True, False), (False, True)])
 def test_bifpn_node_backward_in_one_pass(up1, three):
     """mi355_bifpn_node_bwd == fusion-weight sums + one scaled accumulate per input (efficientdet.py:213-265)."""
