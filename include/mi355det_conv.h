@@ -141,11 +141,14 @@ typedef struct Mi355LayerDesc {
     int32_t K, C, R, S, Cpad, Kpad;
     int32_t block_begin;     /* first block of this layer in the launch */
     float eps;
-    int32_t atomic;          /* grads: != 0 when another descriptor writes the same dW / dbias
-                                (weights shared across pyramid levels): use atomics */
+    int32_t atomic;          /* grads: 1 = another descriptor writes the same dW / dbias (weights shared across pyramid
+                                levels) and the additions are fp32 atomics; 2 = this descriptor is a non-head member of
+                                a share_next chain: its dW / shared-bias contribution is added by the chain's head */
     int32_t nslabs;          /* grads: G / colsum hold this many split-K slabs (0 or 1: a single buffer) */
     int32_t f32_shadows;     /* prep: != 0 writes w_fwd / w_dgr as fp32 (the fp32-accurate mode) instead of bf16 */
-    int32_t reserved;
+    int32_t share_next;      /* grads: 1-based table index of the next descriptor that writes the same dW (same K, C,
+                                R, S; its own G / slabs / BN), 0 = none.  The head of a chain adds its members in chain
+                                order and stores once: bit-reproducible shared-weight gradients */
     const float* gamma;      /* frozen BN (all four NULL when the layer has no BN) */
     const float* beta;
     const float* mean;

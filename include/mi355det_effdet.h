@@ -88,7 +88,9 @@ typedef struct Mi355FusionDesc { const float* p; float* w; int32_t n; int32_t pa
 int mi355_fusion_weights_table(const Mi355FusionDesc* table, int rows, float eps, void* stream);
 
 /* ... and their backward (gp = d loss / d p from gw = d loss / d w) for all nodes in one launch. */
-typedef struct Mi355FusionBwdDesc { const float* p; const float* gw; float* gp; int32_t n; int32_t pad_; } Mi355FusionBwdDesc;
+typedef struct Mi355FusionBwdDesc { const float* p; const float* gw; float* gp; int32_t n;
+    int32_t nparts;  /* 0: gw = the n sums; >= 1: gw = nparts partial rows of 4 floats (mi355_bifpn_node_bwd) */
+} Mi355FusionBwdDesc;
 int mi355_fusion_weights_bwd_table(const Mi355FusionBwdDesc* table, int rows, float eps, void* stream);
 
 /* The same for every depthwise layer of a plan in one launch: a device-resident table of `n` rows (borrowed device
@@ -158,8 +160,10 @@ int mi355_bifpn_node_dwconv_fwd(const void* in0, const void* in1, int up1, const
                                 const float* w_t, const float* bias, void* out, int N, int H, int W, int C, int k,
                                 void* stream);
 /* The whole backward of a node in one pass: g_i = w[i] * gz (+ g_i when acc_i) for in0, in1 (2x2 sums of gz when up1:
- * g1 is [N][H/2][W/2][C]) and in2 (may be NULL), and gw[i] += <gz, in_i> when gw is non-NULL (efficientdet.py:213-265
- * as autograd differentiates it). */
+ * g1 is [N][H/2][W/2][C]) and in2 (may be NULL); when gw is non-NULL every block stores its partial <gz, in_i> sums
+ * into its own row gw[block][4] (mi355_bifpn_node_bwd_parts rows, plain stores, nothing to zero;
+ * mi355_fusion_weights_bwd_table adds them in order).  (efficientdet.py:213-265 as autograd differentiates it.) */
+int mi355_bifpn_node_bwd_parts(int N, int H, int W, int C, int up1, int* nparts);
 int mi355_bifpn_node_bwd(const void* gz, const void* in0, const void* in1, int up1, const void* in2, const float* w,
                          float* gw, void* g0, int acc0, void* g1, int acc1, void* g2, int acc2, int N, int H, int W, int C,
                          void* stream);

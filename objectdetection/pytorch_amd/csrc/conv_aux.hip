@@ -449,42 +449,73 @@ extern "C" int mi355_prep_weights_table(const Mi355LayerDesc* d_table, int nlaye
     return check_launch("prep_weights_table_kernel");
 }
 
+// sum of the split-K slabs of one 16-B piece of a layer's raw weight gradient, in index order
+__device__ __forceinline__ float4 pg_sum_slabs(const Mi355LayerDesc& d, long long off) {
+    const float4* gp = reinterpret_cast<const float4*>(d.G + off);
+    float4 g4 = gp[0];
+    const long long ss4 = d.slab_stride >> 2;
+    int sl = 1;
+    for (; sl + 4 <= d.nslabs; sl += 4) {                // four slab loads in flight, added in index order
+        const float4 v0 = gp[sl * ss4], v1 = gp[(sl + 1) * ss4], v2 = gp[(sl + 2) * ss4], v3 = gp[(sl + 3) * ss4];
+        g4.x += v0.x; g4.y += v0.y; g4.z += v0.z; g4.w += v0.w;
+        g4.x += v1.x; g4.y += v1.y; g4.z += v1.z; g4.w += v1.w;
+        g4.x += v2.x; g4.y += v2.y; g4.z += v2.z; g4.w += v2.w;
+        g4.x += v3.x; g4.y += v3.y; g4.z += v3.z; g4.w += v3.w;
+    }
+    for (; sl < d.nslabs; ++sl) {
+        const float4 v = gp[sl * ss4];
+        g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
+    }
+    return g4;
+}
+__device__ __forceinline__ float pg_colsum(const Mi355LayerDesc& d, int k) {
+    float cs = d.colsum[k];
+    for (int sl = 1; sl < d.nslabs; ++sl) cs += d.colsum[(long long)sl * d.Kpad + k];
+    return cs;
+}
+__device__ __forceinline__ float pg_scale(const Mi355LayerDesc& d, int k) {
+    return d.gamma ? d.gamma[k] / sqrtf(d.var[k] + d.eps) : 1.0f;
+}
+
+// Descriptors that write the SAME dW (a conv shared by the pyramid levels, each level with its own folded BN, raw
+// gradient and slab count) form a chain (share_next): the head's blocks add the members' contributions in chain
+// order and store once, the members (atomic == 2) only produce their own BN gradients: bit-reproducible, where one
+// atomicAdd per member left the order of the five additions to the scheduler.
 __global__ __launch_bounds__(256) void param_grads_table_kernel(const Mi355LayerDesc* __restrict__ table,
                                                                 int nlayers) {
     const Mi355LayerDesc d = table[find_layer(table, nlayers, blockIdx.x)];
     const int k = blockIdx.x - d.block_begin, tid = threadIdx.x;
     const int T = d.R * d.S;
-    const float sck = d.gamma ? d.gamma[k] / sqrtf(d.var[k] + d.eps) : 1.0f;
+    const float sck = pg_scale(d, k);
+    const bool member = d.atomic == 2;
     float dot = 0.0f;
     const int total = T * d.Cpad;
-    // 16-B slab reads (Cpad % 8 == 0, rows and slabs 16-B aligned), slabs summed in index order
-    for (int i4 = tid * 4; i4 < total; i4 += 1024) {
-        const float4* gp = reinterpret_cast<const float4*>(d.G + (long long)k * total + i4);
-        float4 g4 = gp[0];
-        const long long ss4 = d.slab_stride >> 2;
-        int sl = 1;
-        for (; sl + 4 <= d.nslabs; sl += 4) {            // four slab loads in flight, added in index order
-            const float4 v0 = gp[sl * ss4], v1 = gp[(sl + 1) * ss4], v2 = gp[(sl + 2) * ss4], v3 = gp[(sl + 3) * ss4];
-            g4.x += v0.x; g4.y += v0.y; g4.z += v0.z; g4.w += v0.w;
-            g4.x += v1.x; g4.y += v1.y; g4.z += v1.z; g4.w += v1.w;
-            g4.x += v2.x; g4.y += v2.y; g4.z += v2.z; g4.w += v2.w;
-            g4.x += v3.x; g4.y += v3.y; g4.z += v3.z; g4.w += v3.w;
-        }
-        for (; sl < d.nslabs; ++sl) {
-            const float4 v = gp[sl * ss4];
-            g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
-        }
-        const float ge[4] = {g4.x, g4.y, g4.z, g4.w};
-        const int t = i4 / d.Cpad, c0 = i4 - t * d.Cpad;
-        const int r = t / d.S, s = t - r * d.S;
+    // 16-B slab reads (Cpad % 8 == 0, rows and slabs 16-B aligned)
+    if (!member || d.dgamma) {
+        for (int i4 = tid * 4; i4 < total; i4 += 1024) {
+            const float4 g4 = pg_sum_slabs(d, (long long)k * total + i4);
+            float ge[4] = {g4.x, g4.y, g4.z, g4.w};
+            float oe[4] = {g4.x * sck, g4.y * sck, g4.z * sck, g4.w * sck};
+            if (!member) {
+                for (int nx = d.share_next; nx != 0;) {
+                    const Mi355LayerDesc& m = table[nx - 1];
+                    const float sm = pg_scale(m, k);
+                    const float4 h4 = pg_sum_slabs(m, (long long)k * total + i4);
+                    oe[0] += h4.x * sm; oe[1] += h4.y * sm; oe[2] += h4.z * sm; oe[3] += h4.w * sm;
+                    nx = m.share_next;
+                }
+            }
+            const int t = i4 / d.Cpad, c0 = i4 - t * d.Cpad;
+            const int r = t / d.S, s = t - r * d.S;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = c0 + e;
-            if (c >= d.C) continue;
-            const float gv = ge[e];
-            const long long wo = k * d.sk + c * d.sc + r * d.sr + s * d.ss;
-            if (d.dgamma) dot += d.w[wo] * gv;
-            if (d.atomic) atomicAdd(d.dW + wo, gv * sck); else d.dW[wo] += gv * sck;
+            for (int e = 0; e < 4; ++e) {
+                const int c = c0 + e;
+                if (c >= d.C) continue;
+                const long long wo = k * d.sk + c * d.sc + r * d.sr + s * d.ss;
+                if (d.dgamma) dot += d.w[wo] * ge[e];
+                if (member) continue;
+                if (d.atomic) atomicAdd(d.dW + wo, oe[e]); else d.dW[wo] += oe[e];
+            }
         }
     }
     if (d.dgamma || d.dbeta || d.dconv_bias) {
@@ -494,15 +525,29 @@ __global__ __launch_bounds__(256) void param_grads_table_kernel(const Mi355Layer
         if ((tid & 63) == 0) red[tid >> 6] = dot;
         __syncthreads();
         if (tid == 0) {
-            float cs = d.colsum[k];
-            for (int sl = 1; sl < d.nslabs; ++sl) cs += d.colsum[(long long)sl * d.Kpad + k];
+            const float cs = pg_colsum(d, k);
             if (d.dgamma) {
                 const float invstd = 1.0f / sqrtf(d.var[k] + d.eps);
                 const float mu = d.mean[k] - (d.conv_bias ? d.conv_bias[k] : 0.0f);
                 d.dgamma[k] += invstd * ((red[0] + red[1] + red[2] + red[3]) - mu * cs);
             }
-            if (d.dbeta) { if (d.atomic) atomicAdd(d.dbeta + k, cs); else d.dbeta[k] += cs; }
-            if (d.dconv_bias) { if (d.atomic) atomicAdd(d.dconv_bias + k, sck * cs); else d.dconv_bias[k] += sck * cs; }
+            // dbeta is the layer's own BN beta, or (BN-less layer) the conv bias, which the chain shares like dW
+            const bool beta_shared = d.gamma == nullptr;
+            float bsum = cs, csum = sck * cs;
+            if (!member) {
+                for (int nx = d.share_next; nx != 0;) {
+                    const Mi355LayerDesc& m = table[nx - 1];
+                    const float mc = pg_colsum(m, k);
+                    bsum += mc;
+                    csum += pg_scale(m, k) * mc;
+                    nx = m.share_next;
+                }
+            }
+            if (d.dbeta) {
+                if (!beta_shared) d.dbeta[k] += cs;
+                else if (!member) { if (d.atomic) atomicAdd(d.dbeta + k, bsum); else d.dbeta[k] += bsum; }
+            }
+            if (d.dconv_bias && !member) { if (d.atomic) atomicAdd(d.dconv_bias + k, csum); else d.dconv_bias[k] += csum; }
         }
     }
 }

@@ -1685,17 +1685,32 @@ __global__ void fusion_weights_bwd_kernel(const float* p, int n, float eps, cons
     // w_i = r_i / s  ->  dL/dr_j = gw_j / s - dot / s^2 ; relu'
     for (int j = 0; j < n; ++j) gp[j] = p[j] > 0.0f ? (gw[j] / s - dot / (s * s)) : 0.0f;
 }
-__global__ void fusion_weights_bwd_table_kernel(const Mi355FusionBwdDesc* __restrict__ table, int rows, float eps) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const Mi355FusionBwdDesc d = table[r];
+// one wave per node: gw is either the three sums themselves (nparts == 0) or `nparts` partial rows of 4 floats written by
+// the blocks of mi355_bifpn_node_bwd; lane l adds rows l, l + 64, ... in order and the lanes are combined by a fixed
+// shuffle tree: bit-reproducible
+__global__ __launch_bounds__(64) void fusion_weights_bwd_table_kernel(const Mi355FusionBwdDesc* __restrict__ table, int rows, float eps) {
+    const Mi355FusionBwdDesc d = table[blockIdx.x];
+    const int lane = threadIdx.x;
+    float g[3] = {0.0f, 0.0f, 0.0f};
+    if (d.nparts >= 1) {
+        for (int b = lane; b < d.nparts; b += 64)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) g[i] += d.gw[b * 4 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) g[i] += __shfl_xor(g[i], o, 64);
+    } else {
+        for (int i = 0; i < d.n; ++i) g[i] = d.gw[i];
+    }
+    if (lane != 0) return;
     float s = eps, dot = 0.0f;
-    for (int i = 0; i < d.n; ++i) { const float v = fmaxf(d.p[i], 0.0f); s += v; dot += d.gw[i] * v; }
-    for (int j = 0; j < d.n; ++j) d.gp[j] = d.p[j] > 0.0f ? (d.gw[j] / s - dot / (s * s)) : 0.0f;
+    for (int i = 0; i < d.n; ++i) { const float v = fmaxf(d.p[i], 0.0f); s += v; dot += g[i] * v; }
+    for (int j = 0; j < d.n; ++j) d.gp[j] = d.p[j] > 0.0f ? (g[j] / s - dot / (s * s)) : 0.0f;
 }
 extern "C" int mi355_fusion_weights_bwd_table(const Mi355FusionBwdDesc* table, int rows, float eps, void* stream) {
     MI355_REQUIRE(table && rows > 0, "fusion_weights_bwd_table: bad args");
-    hipLaunchKernelGGL(fusion_weights_bwd_table_kernel, dim3(blocks_for(rows)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(fusion_weights_bwd_table_kernel, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream,
                        table, rows, eps);
     return check_launch("fusion_weights_bwd_table_kernel");
 }
@@ -1776,7 +1791,7 @@ extern "C" int mi355_bifpn_node_wgrad(const void* gz, const void* in0, const voi
 // The whole backward of a BiFPN node in one pass over gz (a node's backward was its fusion-weight reduction plus one
 // axpy launch per input: 4-5 launches of 3-8 us for 2-3 MB of tensors): g_i (+)= w_i * gz for the three inputs (the
 // half-resolution input of a top-down node takes the sum of its 2 x 2 gz pixels: a thread owns one such quad, so
-// nothing is added across threads) and gw_i += <gz, in_i> (block sums, one atomic per block and weight).
+// nothing is added across threads) and the block's partial <gz, in_i> sums go to its own row of gw (no atomics: bit-reproducible).
 template <typename T>
 __global__ __launch_bounds__(256) void bifpn_node_bwd_kernel(const T* __restrict__ gz, const T* __restrict__ in0,
                                                              const T* __restrict__ in1, int up1,
@@ -1847,8 +1862,16 @@ __global__ __launch_bounds__(256) void bifpn_node_bwd_kernel(const T* __restrict
         }
         if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d0; red[1][threadIdx.x >> 6] = d1; red[2][threadIdx.x >> 6] = d2; }
         __syncthreads();
-        if (threadIdx.x < 3) atomicAdd(gw + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+        // this block's row of the partial sums (plain stores; mi355_fusion_weights_bwd_table adds the rows in order)
+        if (threadIdx.x < 3) gw[(long long)blockIdx.x * 4 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
     }
+}
+
+extern "C" int mi355_bifpn_node_bwd_parts(int N, int H, int W, int C, int up1, int* nparts) {
+    MI355_REQUIRE(nparts && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "bifpn_node_bwd_parts: bad args");
+    const int step = up1 ? 2 : 1;
+    *nparts = (int)blocks_for((long long)N * (H / step) * (W / step) * (C / 8));
+    return MI355_OK;
 }
 
 template <typename T>

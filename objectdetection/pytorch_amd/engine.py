@@ -888,7 +888,7 @@ class RetinaPlan(object):
         tab = self.pgrad_tables.get(key)
         if tab is None:
             self._carve_grads(arena)
-            seen, descs, nb = {}, [], 0
+            seen, descs, nb, chain_tail = {}, [], 0, {}
             for s in self.pgrad_specs:
                 seen[id(s.conv)] = seen.get(id(s.conv), 0) + 1
             for s in self.pgrad_specs:
@@ -899,6 +899,16 @@ class RetinaPlan(object):
                 d.block_begin = nb
                 nb += s.K
                 descs.append(d)
+                if d.atomic and self.deterministic:
+                    # descriptors that write the same dW (a conv shared by the pyramid levels): a chain in table order,
+                    # the head adds the members' slabs in that order and stores once (no atomics: bit-reproducible)
+                    prev = chain_tail.get(id(s.conv))
+                    if prev is None:
+                        d.atomic = 0
+                    else:
+                        descs[prev].share_next = len(descs)          # 1-based index of this descriptor
+                        d.atomic = 2
+                    chain_tail[id(s.conv)] = len(descs) - 1
             tab = (ops_conv.upload_table(descs, self.dev), len(descs), nb) if descs else None
             self.pgrad_tables[key] = tab or ()
         if not tab:

@@ -64,7 +64,7 @@ class FusionDesc(ctypes.Structure):
 
 class FusionBwdDesc(ctypes.Structure):
     """Mi355FusionBwdDesc (include/mi355det_effdet.h)."""
-    _fields_ = [('p', c_vp), ('gw', c_vp), ('gp', c_vp), ('n', c_int), ('pad_', c_int)]
+    _fields_ = [('p', c_vp), ('gw', c_vp), ('gp', c_vp), ('n', c_int), ('nparts', c_int)]
 
 
 class SeSpec(object):
@@ -450,8 +450,11 @@ class EffDetPlan(RetinaPlan):
             gz = self.grad(z)
             gw = None
             if param is not None:
-                gw = self._zero_bwd_alloc(4)
-                self._fusion_bwd.append((param, n, gw))      # all nodes: one table launch behind the backward list
+                npt = ctypes.c_int()
+                _lib.call('mi355_bifpn_node_bwd_parts', c_int(N), c_int(H), c_int(W), c_int(C), c_int(int(up1)),
+                          ctypes.byref(npt))
+                gw = self.new((npt.value, 4), torch.float32, zero=True)   # per-block partial rows, summed in order
+                self._fusion_bwd.append((param, n, gw, npt.value))      # all nodes: one table launch behind the backward list
             # the three input gradients and the fusion-weight sums in ONE pass over gz
             g0, a0 = self.grad(in0), not self.first_write(in0)
             g1, a1 = self.grad(in1), not self.first_write(in1)
@@ -787,8 +790,8 @@ class EffDetPlan(RetinaPlan):
             ftabs = self.__dict__.setdefault('_fusion_bwd_tables', {})
             ftab = ftabs.get(arena)
             if ftab is None:
-                rows = [FusionBwdDesc(p.data_ptr(), gw.data_ptr(), self.grad_view(p, arena).data_ptr(), n, 0)
-                        for p, n, gw in self._fusion_bwd]
+                rows = [FusionBwdDesc(p.data_ptr(), gw.data_ptr(), self.grad_view(p, arena).data_ptr(), n, npt)
+                        for p, n, gw, npt in self._fusion_bwd]
                 arr = (FusionBwdDesc * len(rows))(*rows)
                 ftab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(self.dev)
                 ftabs[arena] = ftab

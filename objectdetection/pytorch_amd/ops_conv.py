@@ -37,7 +37,7 @@ class LayerDesc(ctypes.Structure):
     _fields_ = [('w', c_vp), ('sk', c_i64), ('sc', c_i64), ('sr', c_i64), ('ss', c_i64),
                 ('K', c_int), ('C', c_int), ('R', c_int), ('S', c_int), ('Cpad', c_int), ('Kpad', c_int),
                 ('block_begin', c_int), ('eps', c_f32), ('atomic', c_int), ('nslabs', c_int),
-                ('f32_shadows', c_int), ('reserved', c_int),
+                ('f32_shadows', c_int), ('share_next', c_int),
                 ('gamma', c_vp), ('beta', c_vp), ('mean', c_vp), ('var', c_vp), ('conv_bias', c_vp),
                 ('scale', c_vp), ('shift', c_vp), ('w_fwd', c_vp), ('w_dgr', c_vp),
                 ('G', c_vp), ('colsum', c_vp), ('dW', c_vp), ('dgamma', c_vp), ('dbeta', c_vp),

@@ -142,11 +142,9 @@ def test_training_step_properties_at_other_config_sizes(monkeypatch, arch, size,
     l1, g1 = run(img, ann)
     l2, g2 = run(img, ann)
     assert A_positive(l1)
-    if retina:
-        assert torch.equal(l1, l2) and torch.equal(g1, g2)                # slab split-K: bit-reproducible
-    else:                                                                  # (shared-head dW / SE sums still use fp32 atomics)
-        assert torch.equal(l1, l2)
-        assert float((g1 - g2).norm() / g1.norm()) <= 1e-5
+    # bit-reproducible: slab split-K weight gradients; EfficientDet: depthwise dW / column sums as per-block partial rows,
+    # squeeze-excite FC and fusion-weight gradients as ordered sums (no fp32 atomics anywhere in the step)
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
     lh, gh = run(imgh, annh)
     # (the half-batch launches take other tile shapes / slab counts: bf16 activations differ in the last bit, and
     #  ~100 bf16 layers of EfficientDet amplify that more than RetinaNet's ~60)
