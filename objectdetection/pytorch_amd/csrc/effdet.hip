@@ -1187,23 +1187,40 @@ __global__ void dw_param_grads_kernel(const float* __restrict__ G_t, const float
 // All depthwise layers of a plan in ONE launch: blockIdx.y = row of the device-resident descriptor table
 // (48 launches of ~10 us each at the end of the EfficientDet-D0 backward otherwise).  A layer's tap sums G_t and dy
 // column sums arrive as `nslabs` partial rows `slab_stride` floats apart (mi355_dwconv_wgrad_slabs; 1 row for the
-// atomic path): a block owns 64 channels, its four 64-lane parts each add a contiguous quarter of the rows in index
-// order and the quarters are combined in a fixed order: bit-reproducible.
-constexpr int DWG_MAXT = 25;
-__global__ __launch_bounds__(256) void dw_param_grads_table_kernel(const Mi355DwGradDesc* __restrict__ table) {
-    __shared__ float s_part[3][DWG_MAXT + 1][64];
+// atomic path): a block owns 32 channels, its 16 parts each add a contiguous sixteenth of the rows in index order
+// and the parts are combined in a fixed order: bit-reproducible.
+constexpr int DWG_MAXT = 25, DWG_CH = 32, DWG_PARTS = 16;
+__global__ __launch_bounds__(DWG_CH * DWG_PARTS) void dw_param_grads_table_kernel(const Mi355DwGradDesc* __restrict__ table) {
+    __shared__ float s_part[DWG_PARTS - 1][DWG_MAXT + 1][DWG_CH];
     const Mi355DwGradDesc d = table[blockIdx.y];
-    if ((int)blockIdx.x * 64 >= d.C) return;                  // (uniform per block)
-    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    if ((int)blockIdx.x * DWG_CH >= d.C) return;               // (uniform per block)
+    const int cl = threadIdx.x % DWG_CH, part = threadIdx.x / DWG_CH;
+    const int c = blockIdx.x * DWG_CH + cl;
     const bool live = c < d.C;
     const int nsl = d.nslabs > 0 ? d.nslabs : 1;
-    const int lo = (int)((long long)nsl * part / 4), hi = (int)((long long)nsl * (part + 1) / 4);
+    const int lo = (int)((long long)nsl * part / DWG_PARTS), hi = (int)((long long)nsl * (part + 1) / DWG_PARTS);
     float g[DWG_MAXT + 1];
 #pragma unroll
     for (int t = 0; t <= DWG_MAXT; ++t) g[t] = 0.0f;
     if (live) {
-        for (int sl = lo; sl < hi; ++sl) {
+        // (a thread adds its slabs in index order; two slabs' loads are in flight together: the loop is one round trip
+        //  per iteration, 512 slabs on 4 parts took 0.5 ms per step)
+        int sl = lo;
+        for (; sl + 2 <= hi; sl += 2) {
+            const float* r0 = d.G_t + (long long)sl * d.slab_stride;
+            const float* r1 = r0 + d.slab_stride;
+            float v0[DWG_MAXT + 1], v1[DWG_MAXT + 1];
+#pragma unroll
+            for (int t = 0; t < DWG_MAXT; ++t) {
+                v0[t] = t < d.T ? r0[t * d.C + c] : 0.0f;
+                v1[t] = t < d.T ? r1[t * d.C + c] : 0.0f;
+            }
+            v0[DWG_MAXT] = d.colsum ? d.colsum[(long long)sl * d.slab_stride + c] : 0.0f;
+            v1[DWG_MAXT] = d.colsum ? d.colsum[(long long)(sl + 1) * d.slab_stride + c] : 0.0f;
+#pragma unroll
+            for (int t = 0; t <= DWG_MAXT; ++t) g[t] = (g[t] + v0[t]) + v1[t];
+        }
+        for (; sl < hi; ++sl) {
             const float* row = d.G_t + (long long)sl * d.slab_stride;
 #pragma unroll
             for (int t = 0; t < DWG_MAXT; ++t)
@@ -1217,8 +1234,11 @@ __global__ __launch_bounds__(256) void dw_param_grads_table_kernel(const Mi355Dw
     }
     __syncthreads();
     if (part != 0 || !live) return;
+#pragma unroll 1
+    for (int q = 0; q < DWG_PARTS - 1; ++q) {                                     // fixed order
 #pragma unroll
-    for (int t = 0; t <= DWG_MAXT; ++t) g[t] = ((g[t] + s_part[0][t][cl]) + s_part[1][t][cl]) + s_part[2][t][cl];
+        for (int t = 0; t <= DWG_MAXT; ++t) g[t] += s_part[q][t][cl];
+    }
     const float sc = d.scale ? d.scale[c] : 1.0f;
     float dot = 0.0f;
 #pragma unroll
@@ -1239,8 +1259,8 @@ __global__ __launch_bounds__(256) void dw_param_grads_table_kernel(const Mi355Dw
 
 extern "C" int mi355_dw_param_grads_table(const Mi355DwGradDesc* table, int n, int max_c, void* stream) {
     MI355_REQUIRE(table && n > 0 && n <= 65535 && max_c > 0, "dw_param_grads_table: bad args");
-    hipLaunchKernelGGL(dw_param_grads_table_kernel, dim3((unsigned)((max_c + 63) / 64), (unsigned)n), dim3(256), 0,
-                       (hipStream_t)stream, table);
+    hipLaunchKernelGGL(dw_param_grads_table_kernel, dim3((unsigned)((max_c + DWG_CH - 1) / DWG_CH), (unsigned)n),
+                       dim3(DWG_CH * DWG_PARTS), 0, (hipStream_t)stream, table);
     return check_launch("dw_param_grads_table_kernel");
 }
 
