@@ -449,29 +449,45 @@ extern "C" int mi355_prep_weights_table(const Mi355LayerDesc* d_table, int nlaye
     return check_launch("prep_weights_table_kernel");
 }
 
-// sum of the split-K slabs of one 16-B piece of a layer's raw weight gradient, in index order
-__device__ __forceinline__ float4 pg_sum_slabs(const Mi355LayerDesc& d, long long off) {
+// sum of slabs [lo, hi) of one 16-B piece of a layer's raw weight gradient, in index order
+__device__ __forceinline__ float4 pg_sum_slabs(const Mi355LayerDesc& d, long long off, int lo, int hi) {
     const float4* gp = reinterpret_cast<const float4*>(d.G + off);
-    float4 g4 = gp[0];
     const long long ss4 = d.slab_stride >> 2;
-    int sl = 1;
-    for (; sl + 4 <= d.nslabs; sl += 4) {                // four slab loads in flight, added in index order
+    float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sl = lo;
+    for (; sl + 4 <= hi; sl += 4) {                      // four slab loads in flight, added in index order
         const float4 v0 = gp[sl * ss4], v1 = gp[(sl + 1) * ss4], v2 = gp[(sl + 2) * ss4], v3 = gp[(sl + 3) * ss4];
         g4.x += v0.x; g4.y += v0.y; g4.z += v0.z; g4.w += v0.w;
         g4.x += v1.x; g4.y += v1.y; g4.z += v1.z; g4.w += v1.w;
         g4.x += v2.x; g4.y += v2.y; g4.z += v2.z; g4.w += v2.w;
         g4.x += v3.x; g4.y += v3.y; g4.z += v3.z; g4.w += v3.w;
     }
-    for (; sl < d.nslabs; ++sl) {
+    for (; sl < hi; ++sl) {
         const float4 v = gp[sl * ss4];
         g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
     }
     return g4;
 }
-__device__ __forceinline__ float pg_colsum(const Mi355LayerDesc& d, int k) {
-    float cs = d.colsum[k];
-    for (int sl = 1; sl < d.nslabs; ++sl) cs += d.colsum[(long long)sl * d.Kpad + k];
-    return cs;
+// this part's share of a descriptor's slabs (nslabs 0 / 1: a single buffer)
+__device__ __forceinline__ void pg_range(const Mi355LayerDesc& d, int part, int parts, int& lo, int& hi) {
+    const int nsl = d.nslabs > 0 ? d.nslabs : 1;
+    lo = (int)((long long)nsl * part / parts);
+    hi = (int)((long long)nsl * (part + 1) / parts);
+}
+// sum over the slabs of a layer's dy column sum for channel k, by the whole block: thread t adds its contiguous share
+// of the slabs in index order, the shares are combined by a fixed shuffle tree and the four waves in order (every
+// thread gets the result).  (One thread walking 1024 slabs was a 1024-deep chain of dependent loads.)
+__device__ __forceinline__ float pg_colsum(const Mi355LayerDesc& d, int k, int tid, float* s_red) {
+    const int nsl = d.nslabs > 0 ? d.nslabs : 1;
+    const int lo = (int)((long long)nsl * tid / 256), hi = (int)((long long)nsl * (tid + 1) / 256);
+    float v = 0.0f;
+    for (int sl = lo; sl < hi; ++sl) v += d.colsum[(long long)sl * d.Kpad + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 __device__ __forceinline__ float pg_scale(const Mi355LayerDesc& d, int k) {
     return d.gamma ? d.gamma[k] / sqrtf(d.var[k] + d.eps) : 1.0f;
@@ -490,58 +506,99 @@ __global__ __launch_bounds__(256) void param_grads_table_kernel(const Mi355Layer
     const bool member = d.atomic == 2;
     float dot = 0.0f;
     const int total = T * d.Cpad;
-    // 16-B slab reads (Cpad % 8 == 0, rows and slabs 16-B aligned)
+    // 16-B slab reads (Cpad % 8 == 0, rows and slabs 16-B aligned).  A row of few pieces (EfficientDet's 1x1 convs:
+    // 4-36 pieces, but up to 1024 slabs of the 256 x 256 maps) leaves most of the block idle behind a chain of
+    // dependent slab loads (0.27 ms per D0 step): the idle threads take contiguous parts of the slab range, the parts
+    // are combined through LDS in part order (bit-reproducible).
+    const int nvec = total >> 2;
+    int lanes = 256, parts = 1;
+    while (parts < 16 && (lanes >> 1) >= nvec) { lanes >>= 1; parts <<= 1; }      // lanes * parts == 256
+    const int part = tid / lanes, v0 = tid - part * lanes;
+    __shared__ float4 s_o[256];
+    __shared__ float s_d[256];
     if (!member || d.dgamma) {
-        for (int i4 = tid * 4; i4 < total; i4 += 1024) {
-            const float4 g4 = pg_sum_slabs(d, (long long)k * total + i4);
-            float ge[4] = {g4.x, g4.y, g4.z, g4.w};
-            float oe[4] = {g4.x * sck, g4.y * sck, g4.z * sck, g4.w * sck};
-            if (!member) {
-                for (int nx = d.share_next; nx != 0;) {
-                    const Mi355LayerDesc& m = table[nx - 1];
-                    const float sm = pg_scale(m, k);
-                    const float4 h4 = pg_sum_slabs(m, (long long)k * total + i4);
-                    oe[0] += h4.x * sm; oe[1] += h4.y * sm; oe[2] += h4.z * sm; oe[3] += h4.w * sm;
-                    nx = m.share_next;
+        for (int vb = 0; vb < nvec; vb += lanes) {
+            const int i4 = (vb + v0) * 4;
+            const bool act = vb + v0 < nvec;
+            float oe[4] = {0.f, 0.f, 0.f, 0.f};
+            float dp = 0.0f;
+            int c0 = 0, r = 0, sx = 0;
+            if (act) {
+                int lo, hi;
+                pg_range(d, part, parts, lo, hi);
+                const float4 g4 = pg_sum_slabs(d, (long long)k * total + i4, lo, hi);
+                const float ge[4] = {g4.x, g4.y, g4.z, g4.w};
+                oe[0] = g4.x * sck; oe[1] = g4.y * sck; oe[2] = g4.z * sck; oe[3] = g4.w * sck;
+                if (!member) {
+                    for (int nx = d.share_next; nx != 0;) {
+                        const Mi355LayerDesc& m = table[nx - 1];
+                        const float sm = pg_scale(m, k);
+                        pg_range(m, part, parts, lo, hi);
+                        const float4 h4 = pg_sum_slabs(m, (long long)k * total + i4, lo, hi);
+                        oe[0] += h4.x * sm; oe[1] += h4.y * sm; oe[2] += h4.z * sm; oe[3] += h4.w * sm;
+                        nx = m.share_next;
+                    }
+                }
+                const int t = i4 / d.Cpad;
+                c0 = i4 - t * d.Cpad;
+                r = t / d.S; sx = t - r * d.S;
+                if (d.dgamma) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c0 + e < d.C) dp += d.w[k * d.sk + (c0 + e) * d.sc + r * d.sr + sx * d.ss] * ge[e];
                 }
             }
-            const int t = i4 / d.Cpad, c0 = i4 - t * d.Cpad;
-            const int r = t / d.S, s = t - r * d.S;
+            if (parts > 1) {                               // (uniform)
+                s_o[tid] = make_float4(oe[0], oe[1], oe[2], oe[3]);
+                s_d[tid] = dp;
+                __syncthreads();
+                if (part == 0 && act) {
+                    for (int q = 1; q < parts; ++q) {
+                        const float4 o = s_o[q * lanes + v0];
+                        oe[0] += o.x; oe[1] += o.y; oe[2] += o.z; oe[3] += o.w;
+                        dp += s_d[q * lanes + v0];
+                    }
+                }
+                __syncthreads();
+            }
+            if (part == 0 && act) {
+                dot += dp;
+                if (!member) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = c0 + e;
-                if (c >= d.C) continue;
-                const long long wo = k * d.sk + c * d.sc + r * d.sr + s * d.ss;
-                if (d.dgamma) dot += d.w[wo] * ge[e];
-                if (member) continue;
-                if (d.atomic) atomicAdd(d.dW + wo, oe[e]); else d.dW[wo] += oe[e];
+                    for (int e = 0; e < 4; ++e) {
+                        if (c0 + e >= d.C) continue;
+                        const long long wo = k * d.sk + (c0 + e) * d.sc + r * d.sr + sx * d.ss;
+                        if (d.atomic) atomicAdd(d.dW + wo, oe[e]); else d.dW[wo] += oe[e];
+                    }
+                }
             }
         }
     }
-    if (d.dgamma || d.dbeta || d.dconv_bias) {
+    if (d.dgamma || d.dbeta || d.dconv_bias) {             // (uniform per block)
         __shared__ float red[4];
+        __shared__ float cred[4];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o, 64);
         if ((tid & 63) == 0) red[tid >> 6] = dot;
+        const float cs = pg_colsum(d, k, tid, cred);
+        // dbeta is the layer's own BN beta, or (BN-less layer) the conv bias, which the chain shares like dW
+        const bool beta_shared = d.gamma == nullptr;
+        float bsum = cs, csum = sck * cs;
+        if (!member) {
+            for (int nx = d.share_next; nx != 0;) {
+                const Mi355LayerDesc& m = table[nx - 1];
+                const float mc = pg_colsum(m, k, tid, cred);
+                bsum += mc;
+                csum += pg_scale(m, k) * mc;
+                nx = m.share_next;
+            }
+        }
         __syncthreads();
         if (tid == 0) {
-            const float cs = pg_colsum(d, k);
             if (d.dgamma) {
                 const float invstd = 1.0f / sqrtf(d.var[k] + d.eps);
                 const float mu = d.mean[k] - (d.conv_bias ? d.conv_bias[k] : 0.0f);
                 d.dgamma[k] += invstd * ((red[0] + red[1] + red[2] + red[3]) - mu * cs);
-            }
-            // dbeta is the layer's own BN beta, or (BN-less layer) the conv bias, which the chain shares like dW
-            const bool beta_shared = d.gamma == nullptr;
-            float bsum = cs, csum = sck * cs;
-            if (!member) {
-                for (int nx = d.share_next; nx != 0;) {
-                    const Mi355LayerDesc& m = table[nx - 1];
-                    const float mc = pg_colsum(m, k);
-                    bsum += mc;
-                    csum += pg_scale(m, k) * mc;
-                    nx = m.share_next;
-                }
             }
             if (d.dbeta) {
                 if (!beta_shared) d.dbeta[k] += cs;
