@@ -94,6 +94,25 @@ int mi355_nms_workspace_bytes(int K, int64_t* bytes);
  * Suppression test: IoU > iou_thr, areas without +1 (torchvision semantics). */
 int mi355_nms(const float* boxes, const float* scores, int K, float iou_thr, int32_t* keep_out,
               int32_t* d_num_keep, void* workspace, int64_t workspace_bytes, void* stream);
+/* The pieces of mi355_nms, for the two-phase schedule of large candidate sets (objectdetection/pytorch_amd/ops_detect.py
+ * `nms`: greedy NMS compares a box only with KEPT boxes of higher score, so the bit matrix is built for a head of the
+ * sorted candidates, the tail is tested against the head's kept boxes only, and the survivors go round again; same
+ * result as mi355_nms):
+ * mi355_nms_sort: candidates in descending score order (ties: ascending index) -> sorted_boxes [K][4], sorted_idx [K]
+ *   (their original indices); workspace >= 8 * next_pow2(max(K, 2048)) bytes.
+ * mi355_nms_presorted: the matrix NMS over boxes already in that order; kept ORIGINAL indices (sorted_idx) are written
+ *   to keep_out from 0 (append == 0) or appended behind *d_num_keep.
+ * mi355_nms_filter_tail: the tail boxes (sorted, with their original indices) that no box keep[kept_begin ..
+ *   *d_num_keep) suppresses (boxes = the ORIGINAL box array keep indexes), compacted in order -> out_boxes / out_idx,
+ *   count -> *d_out_count; workspace >= 12 * ceil(Kt / 64) + 64 bytes. */
+int mi355_nms_sort(const float* boxes, const float* scores, int K, float* sorted_boxes, int32_t* sorted_idx,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+int mi355_nms_presorted_workspace_bytes(int K, int64_t* bytes);
+int mi355_nms_presorted(const float* sorted_boxes, const int32_t* sorted_idx, int K, float iou_thr, int32_t* keep_out,
+                        int32_t* d_num_keep, int append, void* workspace, int64_t workspace_bytes, void* stream);
+int mi355_nms_filter_tail(const float* boxes, const int32_t* keep, const int32_t* d_num_keep, int kept_begin,
+                          const float* tail_boxes, const int32_t* tail_idx, int Kt, float iou_thr, float* out_boxes,
+                          int32_t* out_idx, int32_t* d_out_count, void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -830,6 +830,19 @@ __device__ __forceinline__ float bcast(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+// IoU(a, b) > thr exactly as `iou > thr` on the correctly rounded quotient (see the mask kernel's comment)
+__device__ __forceinline__ bool iou_over(const float4 a, float area_a, float bx, float by, float bz, float bw,
+                                         float area_b, float thr, float lo, float hi) {
+    const float w = fmaxf(fminf(a.z, bz) - fmaxf(a.x, bx), 0.0f);
+    const float h = fmaxf(fminf(a.w, bw) - fmaxf(a.y, by), 0.0f);
+    const float inter = w * h;
+    const float uni = (area_a + area_b) - inter;
+    const float q = inter * __builtin_amdgcn_rcpf(uni);
+    bool over = q > hi;
+    if (!(q > hi) && !(q < lo)) over = __fdiv_rn(inter, uni) > thr;     // near the threshold (or NaN): exact
+    return over;
+}
+
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float4* __restrict__ sb, int K, int W,
                                                        float thr, unsigned long long* __restrict__ mask) {
     const int it = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
@@ -846,13 +859,7 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float4* __restrict_
         auto pair = [&](int c) {
             const float bx = bcast(mine.x, c), by = bcast(mine.y, c), bz = bcast(mine.z, c), bw = bcast(mine.w, c);
             const float area_b = bcast(area_m, c);
-            const float w = fmaxf(fminf(a.z, bz) - fmaxf(a.x, bx), 0.0f);
-            const float h = fmaxf(fminf(a.w, bw) - fmaxf(a.y, by), 0.0f);
-            const float inter = w * h;
-            const float uni = (area_a + area_b) - inter;
-            const float q = inter * __builtin_amdgcn_rcpf(uni);
-            bool over = q > hi;
-            if (!(q > hi) && !(q < lo)) over = __fdiv_rn(inter, uni) > thr;     // near the threshold (or NaN): exact
+            const bool over = iou_over(a, area_a, bx, by, bz, bw, area_b, thr, lo, hi);
             if (j0 + c > i && over) bits |= (1ull << c);
         };
         if (j0 + 64 <= K) {                                  // full column tile: fixed trip count, unrolled
@@ -962,12 +969,182 @@ __global__ __launch_bounds__(256) void nms_propagate_kernel(const unsigned long 
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// ---- two-phase NMS for large candidate sets --------------------------------------------------------------------
+// Greedy NMS only ever compares a box with KEPT boxes of higher score.  With tens of thousands of candidates almost all
+// of the K^2/2 pairs of the full bit matrix involve a box that is itself suppressed (46 706 random-initialised
+// candidates: 4 052 kept, 1.09e9 pairs, 1.1 ms).  The host wrapper (ops_detect.nms) therefore runs the matrix NMS on a
+// HEAD of the sorted candidates, tests the whole TAIL against the boxes the head kept (mi355_nms_filter_tail: tail x
+// kept pairs only), compacts the survivors in order, and repeats on them: exact, because a tail box that a head-kept box
+// suppresses is never kept and so never suppresses anything itself.
+__global__ __launch_bounds__(256) void nms_filter_kernel(const float4* __restrict__ boxes, const int32_t* __restrict__ keep,
+                                                         const int32_t* __restrict__ d_nk, int kept_begin,
+                                                         const float4* __restrict__ tail, int Kt, float thr,
+                                                         unsigned long long* __restrict__ surv_words) {
+    __shared__ unsigned long long s_rem[4];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = blockIdx.x * 64 + lane;
+    const float4 a = t < Kt ? tail[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float area_a = (a.z - a.x) * (a.w - a.y);
+    const float lo = thr * (1.0f - 1e-5f), hi = thr * (1.0f + 1e-5f);
+    const int nk = *d_nk;
+    bool removed = false;
+    for (int j0 = kept_begin + wv * 64; j0 < nk; j0 += 256) {
+        const int j = j0 + lane;
+        const float4 mine = j < nk ? boxes[keep[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float area_m = (mine.z - mine.x) * (mine.w - mine.y);
+        const int n = min(64, nk - j0);
+        for (int c = 0; c < n; ++c) {
+            const float bx = bcast(mine.x, c), by = bcast(mine.y, c), bz = bcast(mine.z, c), bw = bcast(mine.w, c);
+            removed |= iou_over(a, area_a, bx, by, bz, bw, bcast(area_m, c), thr, lo, hi);
+        }
+    }
+    const unsigned long long r = __ballot(removed);
+    if (lane == 0) s_rem[wv] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long rem = (s_rem[0] | s_rem[1]) | (s_rem[2] | s_rem[3]);
+        const int nb = min(64, Kt - blockIdx.x * 64);
+        const unsigned long long valid = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+        surv_words[blockIdx.x] = ~rem & valid;
+    }
+}
+
+// one block: exclusive prefix sum of the survivors per 64-box word -> word_off[w], total -> *d_count
+__global__ __launch_bounds__(1024) void nms_survivor_scan_kernel(const unsigned long long* __restrict__ surv_words, int Wt,
+                                                                 int32_t* __restrict__ word_off, int32_t* __restrict__ d_count) {
+    __shared__ int s_sum[1024];
+    const int tid = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < Wt; base += 1024) {
+        const int w = base + tid;
+        const int c = w < Wt ? __popcll(surv_words[w]) : 0;
+        s_sum[tid] = c;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {                 // Hillis-Steele inclusive scan
+            const int v = tid >= o ? s_sum[tid - o] : 0;
+            __syncthreads();
+            s_sum[tid] += v;
+            __syncthreads();
+        }
+        if (w < Wt) word_off[w] = carry + s_sum[tid] - c;
+        const int tot = s_sum[1023];
+        __syncthreads();
+        carry += tot;
+    }
+    if (tid == 0) *d_count = carry;
+}
+
+__global__ void nms_survivor_scatter_kernel(const unsigned long long* __restrict__ surv_words,
+                                            const int32_t* __restrict__ word_off, const float4* __restrict__ tail,
+                                            const int32_t* __restrict__ tail_idx, int Kt, float4* __restrict__ out_boxes,
+                                            int32_t* __restrict__ out_idx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Kt) return;
+    const unsigned long long w = surv_words[t >> 6];
+    const int b = t & 63;
+    if (!((w >> b) & 1ull)) return;
+    const int pos = word_off[t >> 6] + __popcll(w & ((1ull << b) - 1ull));
+    out_boxes[pos] = tail[t];
+    out_idx[pos] = tail_idx[t];
+}
+
+extern "C" int mi355_nms_filter_tail(const float* boxes, const int32_t* keep, const int32_t* d_num_keep, int kept_begin,
+                                     const float* tail_boxes, const int32_t* tail_idx, int Kt, float iou_thr,
+                                     float* out_boxes, int32_t* out_idx, int32_t* d_out_count, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    MI355_REQUIRE(boxes && keep && d_num_keep && kept_begin >= 0 && tail_boxes && tail_idx && Kt > 0 && out_boxes && out_idx &&
+                  d_out_count && workspace, "nms_filter_tail: bad args");
+    MI355_REQUIRE(((uintptr_t)boxes & 15) == 0 && ((uintptr_t)tail_boxes & 15) == 0 && ((uintptr_t)out_boxes & 15) == 0 &&
+                  ((uintptr_t)workspace & 15) == 0, "nms_filter_tail: alignment");
+    const int Wt = (int)cdiv(Kt, 64);
+    MI355_REQUIRE(workspace_bytes >= (int64_t)Wt * 12 + 64, "nms_filter_tail: workspace %lld < %lld",
+                  (long long)workspace_bytes, (long long)Wt * 12 + 64);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* surv = (unsigned long long*)workspace;
+    int32_t* word_off = (int32_t*)(surv + Wt);
+    hipLaunchKernelGGL(nms_filter_kernel, dim3((unsigned)Wt), dim3(256), 0, st, (const float4*)boxes, keep, d_num_keep,
+                       kept_begin, (const float4*)tail_boxes, Kt, iou_thr, surv);
+    hipLaunchKernelGGL(nms_survivor_scan_kernel, dim3(1), dim3(1024), 0, st, surv, Wt, word_off, d_out_count);
+    hipLaunchKernelGGL(nms_survivor_scatter_kernel, dim3((unsigned)cdiv(Kt, 256)), dim3(256), 0, st, surv, word_off,
+                       (const float4*)tail_boxes, tail_idx, Kt, (float4*)out_boxes, out_idx);
+    return check_launch("nms_filter_tail");
+}
+
 extern "C" int mi355_nms_workspace_bytes(int K, int64_t* bytes) {
     MI355_REQUIRE(K >= 0 && bytes, "nms_workspace_bytes: bad args");
     int64_t K2 = next_pow2(K < SORT_CHUNK ? SORT_CHUNK : K);
     int64_t W = cdiv(K, 64);
     *bytes = K2 * 8 + (int64_t)K * 16 + (int64_t)K * 4 + 64 + W * W * 64 * 8 + 256 + 2 * (W * 8 + 64);
     return MI355_OK;
+}
+
+extern "C" int mi355_nms_sort(const float* boxes, const float* scores, int K, float* sorted_boxes, int32_t* sorted_idx,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+    MI355_REQUIRE(boxes && scores && K > 0 && sorted_boxes && sorted_idx && workspace, "nms_sort: bad args");
+    MI355_REQUIRE(((uintptr_t)boxes & 15) == 0 && ((uintptr_t)sorted_boxes & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
+                  "nms_sort: alignment");
+    const int K2 = next_pow2(K < SORT_CHUNK ? SORT_CHUNK : K);
+    MI355_REQUIRE(workspace_bytes >= (int64_t)K2 * 8, "nms_sort: workspace %lld < %lld", (long long)workspace_bytes,
+                  (long long)K2 * 8);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* keys = (unsigned long long*)workspace;
+    hipLaunchKernelGGL(nms_make_keys_kernel, dim3(K2 / 256), dim3(256), 0, st, scores, K, K2, keys);
+    hipLaunchKernelGGL(bitonic_chunk_sort_kernel, dim3(K2 / SORT_CHUNK), dim3(256), 0, st, keys);
+    for (int k = SORT_CHUNK * 2; k <= K2; k <<= 1) {
+        for (int j = k >> 1; j >= SORT_CHUNK; j >>= 1)
+            hipLaunchKernelGGL(bitonic_global_step_kernel, dim3(K2 / 2 / 256), dim3(256), 0, st, keys, K2, k, j);
+        hipLaunchKernelGGL(bitonic_chunk_merge_kernel, dim3(K2 / SORT_CHUNK), dim3(256), 0, st, keys, k);
+    }
+    hipLaunchKernelGGL(nms_gather_boxes_kernel, dim3((unsigned)cdiv(K, 256)), dim3(256), 0, st, keys,
+                       (const float4*)boxes, K, (float4*)sorted_boxes, sorted_idx);
+    return check_launch("nms_sort");
+}
+
+extern "C" int mi355_nms_presorted_workspace_bytes(int K, int64_t* bytes) {
+    MI355_REQUIRE(K >= 0 && bytes, "nms_presorted_workspace_bytes: bad args");
+    const int64_t W = cdiv(K, 64);
+    *bytes = W * W * 64 * 8 + 256 + 2 * (W * 8 + 64);
+    return MI355_OK;
+}
+
+// matrix NMS over boxes that are already in descending score order; the kept ORIGINAL indices (sorted_idx) are appended
+// to keep_out behind *d_num_keep (append != 0) or written from 0
+extern "C" int mi355_nms_presorted(const float* sorted_boxes, const int32_t* sorted_idx, int K, float iou_thr,
+                                   int32_t* keep_out, int32_t* d_num_keep, int append, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    MI355_REQUIRE(sorted_boxes && sorted_idx && K > 0 && keep_out && d_num_keep && workspace, "nms_presorted: bad args");
+    MI355_REQUIRE(((uintptr_t)sorted_boxes & 15) == 0 && ((uintptr_t)workspace & 15) == 0, "nms_presorted: alignment");
+    int64_t need;
+    mi355_nms_presorted_workspace_bytes(K, &need);
+    if (workspace_bytes < need) return fail(MI355_ENOSPC, "nms_presorted: workspace %lld < %lld",
+                                            (long long)workspace_bytes, (long long)need);
+    hipStream_t st = (hipStream_t)stream;
+    const int W = (int)cdiv(K, 64);
+    char* p = (char*)workspace;
+    unsigned long long* mask = (unsigned long long*)p;              p += (int64_t)W * W * 64 * 8;
+    unsigned long long* removed = (unsigned long long*)p;           p += (((int64_t)W * 8 + 63) / 64) * 64;
+    unsigned long long* kept_bits = (unsigned long long*)p;
+    const float4* sboxes = (const float4*)sorted_boxes;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(W, 4), dim3(256), 0, st, sboxes, K, W, iou_thr, mask);
+    if (hipMemsetAsync(removed, 0, (size_t)W * 8, st) != hipSuccess ||
+        (!append && hipMemsetAsync(d_num_keep, 0, 4, st) != hipSuccess))
+        return fail(MI355_ELAUNCH, "nms: memset failed");
+    static bool attr_set = false;
+    constexpr size_t DIAG_BYTES = (size_t)SW_S * SW_LD * 8;           // 136 KiB of the 160 KiB LDS
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)nms_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_BYTES);
+        attr_set = true;
+    }
+    const int nsteps = (int)cdiv(K, SW_S);
+    for (int step = 0; step < nsteps; ++step) {
+        hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), DIAG_BYTES, st, mask, sorted_idx, K, W, step, removed,
+                           kept_bits, keep_out, d_num_keep);
+        const int rest = W - (step + 1) * SW_T;
+        if (rest > 0)
+            hipLaunchKernelGGL(nms_propagate_kernel, dim3((unsigned)cdiv(rest, 64), SW_T), dim3(256), 0, st, mask, K, W, step,
+                               kept_bits, removed);
+    }
+    return check_launch("nms");
 }
 
 extern "C" int mi355_nms(const float* boxes, const float* scores, int K, float iou_thr,
@@ -986,41 +1163,12 @@ extern "C" int mi355_nms(const float* boxes, const float* scores, int K, float i
     if (workspace_bytes < need) return fail(MI355_ENOSPC, "nms: workspace %lld < %lld",
                                             (long long)workspace_bytes, (long long)need);
     const int K2 = next_pow2(K < SORT_CHUNK ? SORT_CHUNK : K);
-    const int W = (int)cdiv(K, 64);
     char* p = (char*)workspace;
-    unsigned long long* keys = (unsigned long long*)p;  p += (int64_t)K2 * 8;
-    float4* sboxes = (float4*)p;                        p += (int64_t)K * 16;
+    void* keys = p;                                     p += (int64_t)K2 * 8;
+    float* sboxes = (float*)p;                          p += (int64_t)K * 16;
     int32_t* sidx = (int32_t*)p;                        p += (((int64_t)K * 4 + 63) / 64) * 64;
-    unsigned long long* mask = (unsigned long long*)p;              p += (int64_t)W * W * 64 * 8;
-    unsigned long long* removed = (unsigned long long*)p;           p += (((int64_t)W * 8 + 63) / 64) * 64;
-    unsigned long long* kept_bits = (unsigned long long*)p;
-
-    hipLaunchKernelGGL(nms_make_keys_kernel, dim3(K2 / 256), dim3(256), 0, st, scores, K, K2, keys);
-    hipLaunchKernelGGL(bitonic_chunk_sort_kernel, dim3(K2 / SORT_CHUNK), dim3(256), 0, st, keys);
-    for (int k = SORT_CHUNK * 2; k <= K2; k <<= 1) {
-        for (int j = k >> 1; j >= SORT_CHUNK; j >>= 1)
-            hipLaunchKernelGGL(bitonic_global_step_kernel, dim3(K2 / 2 / 256), dim3(256), 0, st, keys, K2, k, j);
-        hipLaunchKernelGGL(bitonic_chunk_merge_kernel, dim3(K2 / SORT_CHUNK), dim3(256), 0, st, keys, k);
-    }
-    hipLaunchKernelGGL(nms_gather_boxes_kernel, dim3((unsigned)cdiv(K, 256)), dim3(256), 0, st, keys,
-                       (const float4*)boxes, K, sboxes, sidx);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(W, 4), dim3(256), 0, st, sboxes, K, W, iou_thr, mask);
-    if (hipMemsetAsync(removed, 0, (size_t)W * 8, st) != hipSuccess || hipMemsetAsync(d_num_keep, 0, 4, st) != hipSuccess)
-        return fail(MI355_ELAUNCH, "nms: memset failed");
-    static bool attr_set = false;
-    constexpr size_t DIAG_BYTES = (size_t)SW_S * SW_LD * 8;           // 136 KiB of the 160 KiB LDS
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)nms_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_BYTES);
-        attr_set = true;
-    }
-    const int nsteps = (int)cdiv(K, SW_S);
-    for (int step = 0; step < nsteps; ++step) {
-        hipLaunchKernelGGL(nms_resolve_kernel, dim3(1), dim3(1024), DIAG_BYTES, st, mask, sidx, K, W, step, removed,
-                           kept_bits, keep_out, d_num_keep);
-        const int rest = W - (step + 1) * SW_T;
-        if (rest > 0)
-            hipLaunchKernelGGL(nms_propagate_kernel, dim3((unsigned)cdiv(rest, 64), SW_T), dim3(256), 0, st, mask, K, W, step,
-                               kept_bits, removed);
-    }
-    return check_launch("nms");
+    const int rc = mi355_nms_sort(boxes, scores, K, sboxes, sidx, keys, (int64_t)K2 * 8, stream);
+    if (rc) return rc;
+    return mi355_nms_presorted(sboxes, sidx, K, iou_thr, keep_out, d_num_keep, 0, p, workspace_bytes - (p - (char*)workspace),
+                               stream);
 }

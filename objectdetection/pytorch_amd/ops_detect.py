@@ -151,17 +151,59 @@ def score_filter(score, thr):
     return idx[:int(cnt.item())]          # host sync, as the reference's boolean indexing
 
 
+NMS_HEAD = 4096          # candidates of the first matrix pass of the two-phase schedule
+NMS_DIRECT_MAX = 8192    # up to here one matrix pass over all candidates
+
+
+def _aligned(nbytes, device):
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+    return ws, ws.data_ptr() + (-ws.data_ptr()) % 256
+
+
 def nms(boxes, scores, iou_threshold):
-    """Same contract as torchvision.ops.nms: int64 indices, descending score."""
+    """Same contract as torchvision.ops.nms: int64 indices, descending score.
+
+    Up to NMS_DIRECT_MAX candidates: one launch sequence (mi355_nms).  More: greedy NMS only compares a box with KEPT
+    boxes of higher score, so the suppression bit matrix is built for a HEAD of the sorted candidates only, the TAIL
+    is tested against the boxes the head kept (tail x kept pairs), and the compacted survivors go round again —
+    46 706 candidates with 4 052 kept: ~0.1e9 IoU tests instead of 1.09e9.  One host read of the survivor count per
+    round (this function ends in one anyway: the reference's boolean indexing)."""
     require_gpu(boxes, scores)
     boxes, scores = _c(boxes), _c(scores)
     K = boxes.shape[0]
-    keep = torch.empty(max(K, 1), dtype=torch.int32, device=boxes.device)
-    cnt = torch.zeros(1, dtype=torch.int32, device=boxes.device)
-    nbytes = ctypes.c_int64()
-    call('mi355_nms_workspace_bytes', c_int(K), ctypes.byref(nbytes))
-    ws = torch.empty(nbytes.value + 256, dtype=torch.uint8, device=boxes.device)
-    off = (-ws.data_ptr()) % 256
-    call('mi355_nms', ptr(boxes), ptr(scores), c_int(K), c_f32(iou_threshold), ptr(keep), ptr(cnt),
-         c_vp(ws.data_ptr() + off), c_i64(nbytes.value), stream_of(boxes))
-    return keep[:int(cnt.item())].long()
+    dev = boxes.device
+    st = stream_of(boxes)
+    keep = torch.empty(max(K, 1), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)          # [kept, survivors of the current round]
+    if K <= NMS_DIRECT_MAX:
+        nbytes = ctypes.c_int64()
+        call('mi355_nms_workspace_bytes', c_int(K), ctypes.byref(nbytes))
+        ws, wp = _aligned(nbytes.value, dev)
+        call('mi355_nms', ptr(boxes), ptr(scores), c_int(K), c_f32(iou_threshold), ptr(keep), ptr(cnt),
+             c_vp(wp), c_i64(nbytes.value), st)
+        return keep[:int(cnt[0].item())].long()
+    k2 = 1 << max(K - 1, 2047).bit_length()
+    sws, swp = _aligned(8 * k2, dev)
+    cur_b = torch.empty((K, 4), dtype=torch.float32, device=dev)
+    cur_i = torch.empty(K, dtype=torch.int32, device=dev)
+    call('mi355_nms_sort', ptr(boxes), ptr(scores), c_int(K), ptr(cur_b), ptr(cur_i), c_vp(swp), c_i64(8 * k2), st)
+    nxt_b, nxt_i = torch.empty_like(cur_b), torch.empty_like(cur_i)
+    pbytes = ctypes.c_int64()
+    call('mi355_nms_presorted_workspace_bytes', c_int(NMS_DIRECT_MAX), ctypes.byref(pbytes))
+    pws, pwp = _aligned(pbytes.value, dev)
+    fws, fwp = _aligned(12 * ((K + 63) // 64) + 64, dev)
+    rem, kept_before, first = K, 0, True
+    while rem > 0:
+        head = rem if rem <= NMS_DIRECT_MAX else NMS_HEAD
+        call('mi355_nms_presorted', ptr(cur_b), ptr(cur_i), c_int(head), c_f32(iou_threshold), ptr(keep), ptr(cnt),
+             c_int(0 if first else 1), c_vp(pwp), c_i64(pbytes.value), st)
+        first = False
+        tail = rem - head
+        if tail == 0:
+            break
+        call('mi355_nms_filter_tail', ptr(boxes), ptr(keep), ptr(cnt), c_int(kept_before),
+             c_vp(cur_b.data_ptr() + 16 * head), c_vp(cur_i.data_ptr() + 4 * head), c_int(tail), c_f32(iou_threshold),
+             ptr(nxt_b), ptr(nxt_i), c_vp(cnt.data_ptr() + 4), c_vp(fwp), c_i64(12 * ((K + 63) // 64) + 64), st)
+        kept_before, rem = (int(v) for v in cnt.tolist())        # the round's host read
+        cur_b, nxt_b, cur_i, nxt_i = nxt_b, cur_b, nxt_i, cur_i
+    return keep[:int(cnt[0].item())].long()

@@ -149,6 +149,20 @@ def test_nms_vs_oracle_bit_exact(dev, n):
     assert np.array_equal(keep.cpu().numpy(), ref_cpu.nms(b, s, 0.5))
 
 
+@pytest.mark.parametrize('n,span', [(8192, 300.0), (8193, 300.0), (12289, 5000.0), (20000, 100.0), (30000, 1500.0)])
+def test_nms_two_phase_schedule(dev, n, span):
+    """Above ops_detect.NMS_DIRECT_MAX candidates the head / filtered-tail schedule runs: sparse boxes (nothing
+    suppressed: every round keeps its whole head and the tail survives), dense ones (almost everything suppressed by the
+    first head) and sizes around the switch must give the one-pass result = the oracle's."""
+    from objectdetection.pytorch_amd import ops_detect
+    rng = np.random.default_rng(n)
+    b = _rand_boxes(rng, n, span=span)
+    s = rng.random(n).astype(np.float32)
+    s[rng.integers(0, n, n // 10)] = 0.25
+    keep = ops_detect.nms(torch.from_numpy(b).to(dev), torch.from_numpy(s).to(dev), 0.5)
+    assert np.array_equal(keep.cpu().numpy(), ref_cpu.nms(b, s, 0.5))
+
+
 def test_nms_edge_cases(dev):
     from objectdetection.pytorch_amd import ops_detect
     b = np.array([[0, 0, 10, 10], [0, 0, 10, 5], [5, 5, 5, 5], [5, 5, 5, 5]], dtype=np.float32)
