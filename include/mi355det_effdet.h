@@ -153,6 +153,11 @@ int mi355_axpy_bf16(const void* src, const float* w, int wi, void* dst, int64_t 
  * per_image = H*W*C elements.  Backward of the branch = the same call on the gradient with addend NULL. */
 int mi355_drop_connect(const void* src, const float* u, float keep, const void* addend, void* dst, int N,
                        int64_t per_image, void* stream);
+/* its backward in one pass over dy: g_branch = dy / keep * floor(keep + u[n]); g_skip = dy (+ g_skip when acc_skip) */
+int mi355_drop_connect_bwd(const void* dy, const float* u, float keep, void* g_branch, void* g_skip, int acc_skip, int N,
+                           int64_t per_image, void* stream);
+int mi355_drop_connect_bwd_f32(const void* dy, const float* u, float keep, void* g_branch, void* g_skip, int acc_skip,
+                               int N, int64_t per_image, void* stream);
 /* mi355_bifpn_node_fwd + mi355_dwconv_fwd(in_swish = 1, stride 1, "same") in ONE launch: z (stored: the backward
  * reads it) is built while the depthwise conv's halo tile is staged; bit-identical to the two launches.
  * (efficientdet.py:213-265: `self.conv6_up(self.swish(weight[0] * p6_in + weight[1] * self.p6_upsample(p7_in)))` ...) */

@@ -1977,6 +1977,51 @@ extern "C" int mi355_drop_connect(const void* src, const float* u, float keep, c
     return check_launch("drop_connect_kernel");
 }
 
+// backward of out = branch / keep * floor(keep + u[n]) + skip in one pass over dy: g_branch = dy / keep * b[n],
+// g_skip (+)= dy (the two launches `drop_connect` + `axpy` read dy twice)
+template <typename T>
+__global__ void drop_connect_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ u, float keep,
+                                        T* __restrict__ g_branch, T* __restrict__ g_skip, int acc_skip,
+                                        long long per_image8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_image8) return;
+    const int n = blockIdx.y;
+    const float b = floorf(keep + u[n]);
+    const long long t = (long long)n * per_image8 + i;
+    float v[8], o[8];
+    load8(dy + t * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = v[e] / keep * b;
+    store8(g_branch + t * 8, o);
+    if (acc_skip) {
+        float a[8];
+        load8(g_skip + t * 8, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += a[e];
+    }
+    store8(g_skip + t * 8, v);
+}
+
+template <typename T>
+static int launch_drop_connect_bwd(const void* dy, const float* u, float keep, void* g_branch, void* g_skip, int acc_skip,
+                                   int N, int64_t per_image, void* stream) {
+    MI355_REQUIRE(dy && u && g_branch && g_skip && N > 0 && N <= 65535 && per_image > 0 && per_image % 8 == 0,
+                  "drop_connect_bwd: bad args (per_image must be a multiple of 8)");
+    MI355_REQUIRE(keep > 0.0f && keep <= 1.0f, "drop_connect_bwd: keep probability %g outside (0, 1]", (double)keep);
+    hipLaunchKernelGGL(drop_connect_bwd_kernel<T>, dim3(blocks_for(per_image / 8), (unsigned)N), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)dy, u, keep, (T*)g_branch, (T*)g_skip, acc_skip,
+                       (long long)(per_image / 8));
+    return check_launch("drop_connect_bwd_kernel");
+}
+extern "C" int mi355_drop_connect_bwd(const void* dy, const float* u, float keep, void* g_branch, void* g_skip,
+                                      int acc_skip, int N, int64_t per_image, void* stream) {
+    return launch_drop_connect_bwd<unsigned short>(dy, u, keep, g_branch, g_skip, acc_skip, N, per_image, stream);
+}
+extern "C" int mi355_drop_connect_bwd_f32(const void* dy, const float* u, float keep, void* g_branch, void* g_skip,
+                                          int acc_skip, int N, int64_t per_image, void* stream) {
+    return launch_drop_connect_bwd<float>(dy, u, keep, g_branch, g_skip, acc_skip, N, per_image, stream);
+}
+
 template <typename T>
 __global__ void upsample_bwd_axpy_kernel(const T* __restrict__ src, const float* __restrict__ w, int wi,
                                          T* __restrict__ dst, int N, int H, int W, int C, int accumulate) {

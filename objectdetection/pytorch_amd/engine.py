@@ -87,7 +87,7 @@ F32_TWINS = {'mi355_conv_gather': 'mi355_conv_gather_f32', 'mi355_conv_wgrad_sla
              'mi355_se_scale': 'mi355_se_scale_f32', 'mi355_se_bwd_reduce': 'mi355_se_bwd_reduce_f32',
              'mi355_se_bwd_apply': 'mi355_se_bwd_apply_f32', 'mi355_bifpn_node_fwd': 'mi355_bifpn_node_fwd_f32',
              'mi355_bifpn_node_wgrad': 'mi355_bifpn_node_wgrad_f32', 'mi355_bifpn_node_bwd': 'mi355_bifpn_node_bwd_f32', 'mi355_axpy_bf16': 'mi355_axpy_f32',
-             'mi355_drop_connect': 'mi355_drop_connect_f32', 'mi355_upsample_bwd_axpy': 'mi355_upsample_bwd_axpy_f32',
+             'mi355_drop_connect': 'mi355_drop_connect_f32', 'mi355_drop_connect_bwd': 'mi355_drop_connect_bwd_f32', 'mi355_upsample_bwd_axpy': 'mi355_upsample_bwd_axpy_f32',
              'mi355_maxpool_same_fwd': 'mi355_maxpool_same_fwd_f32', 'mi355_maxpool_same_bwd': 'mi355_maxpool_same_bwd_f32'}
 # entry points that never see an activation tensor (fp32 vectors / parameter tables): the same in both modes
 F32_NEUTRAL = ('mi355_se_fc', 'mi355_se_fc_bwd', 'mi355_se_slabs', 'mi355_fusion_weights', 'mi355_dw_prep', 'mi355_dw_param',

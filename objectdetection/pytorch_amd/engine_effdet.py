@@ -480,11 +480,11 @@ class EffDetPlan(RetinaPlan):
             if not self.has_grad(out):
                 return
             dy = self.grad(out)
-            self._axpy(dy, None, 0, self.grad(skip), not self.first_write(skip))
+            gs, acc = self.grad(skip), not self.first_write(skip)
             gb = self.grad(branch)
             assert self.first_write(branch)
-            self._step(self.bwd_steps, 'mi355_drop_connect', ptr(dy), ptr(u), c_f32(keep), c_vp(0), ptr(gb),
-                       c_int(N), c_i64(per))
+            self._step(self.bwd_steps, 'mi355_drop_connect_bwd', ptr(dy), ptr(u), c_f32(keep), ptr(gb), ptr(gs),
+                       c_int(int(acc)), c_int(N), c_i64(per))
         self.tape.append(bwd)
         return out
 
