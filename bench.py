@@ -48,7 +48,8 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--depth', type=int, default=50)
-    ap.add_argument('--arch', default='retinanet', help="'retinanet' (headline) or 'efficientdet-dN' (configs[3], [4])")
+    ap.add_argument('--arch', default='retinanet',
+                    help="'retinanet' (headline), 'efficientdet-dN' (configs[3], [4]) or 'ksevendet' / 'ksevendet-panet' (SURVEY 8 f-3)")
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -66,9 +67,22 @@ def parse():
 
 
 def build_model(depth, num_classes, dev, arch='retinanet'):
-    if arch != 'retinanet' and not arch.startswith('efficientdet-d'):
-        raise SystemExit("--arch must be 'retinanet' or 'efficientdet-dN', got %r" % arch)
-    if arch.startswith('efficientdet'):
+    if arch not in ('retinanet', 'ksevendet', 'ksevendet-panet') and not arch.startswith('efficientdet-d'):
+        raise SystemExit("--arch must be 'retinanet', 'ksevendet[-panet]' or 'efficientdet-dN', got %r" % arch)
+    if arch.startswith('ksevendet'):
+        # config/model/ksevendet_resnet.yaml (ResNet trunk of --depth, FPN or PANet-FPN neck, simple heads
+        # with per-level BN over shared convs), frozen BN as train_ksevendet.py runs it
+        import yaml
+        from objectdetection.pytorch_amd.ksevendet.architecture import ksevendet
+        cfg = yaml.safe_load(open(os.path.join(ROOT, 'objectdetection', 'pytorch_amd', 'config', 'model',
+                                               'ksevendet_resnet.yaml')))
+        cfg.pop('architecture')
+        cfg['variant'] = 'resnet%d' % depth
+        cfg['neck'] = 'panet-fpn' if arch.endswith('panet') else 'fpn'
+        model = ksevendet.KSevenDet(cfg, num_classes=num_classes, pretrained=False)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        sd = synth.synth_state_dict(shapes, seed=0, gain=0.78 if depth >= 50 else 0.87)
+    elif arch.startswith('efficientdet'):
         from objectdetection.pytorch_amd.architectures import efficientdet
         model = efficientdet.build_efficientdet(arch, num_classes=num_classes)
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -342,7 +356,9 @@ def main():
             dist.init_process_group(backend)
     num_classes = 80
     model, sd = build_model(args.depth, num_classes, dev, args.arch)
-    name = 'RetinaNet-R%d' % args.depth if args.arch == 'retinanet' else 'EfficientDet-D' + args.arch[-1]
+    name = ('RetinaNet-R%d' % args.depth if args.arch == 'retinanet' else
+            'KSevenDet-R%d-%s' % (args.depth, 'PANetFPN' if args.arch.endswith('panet') else 'FPN') if args.arch.startswith('ksevendet')
+            else 'EfficientDet-D' + args.arch[-1])
     B, S = args.batch, args.size
     # each rank owns its shard of the global batch (weak scaling: per-GPU batch fixed)
     img = torch.from_numpy(synth.synth_images(B, S, S, seed=100 + rank)).to(dev)
@@ -427,7 +443,8 @@ def main():
                    'final_loss': [round(float(v), 5) for v in (loss_acc / (args.warmup + args.steps)).tolist()]},
     }
     plan = model._plans[next(iter(model._plans))]
-    if rank == 0 and not args.no_roofline and args.arch != 'retinanet':
+    conv_bound = args.arch == 'retinanet' or args.arch.startswith('ksevendet')
+    if rank == 0 and not args.no_roofline and not conv_bound:
         # HBM-bound configs (depthwise / SE / BiFPN passes): algorithmic bytes of the step's launches over
         # the step time, against the HBM peak
         nbytes, per_kernel = plan_launch_bytes(plan)
@@ -440,7 +457,7 @@ def main():
                                      % (len(plan.prep_steps) + len(plan.fwd_steps) + len(plan.bwd_steps),
                                         ', '.join('%s %.0f MB' % (k.replace('mi355_', ''), v / 1e6) for k, v in top)),
                            'step_ms_median': round(median_ms, 3)}
-    if rank == 0 and not args.no_roofline and args.arch == 'retinanet':
+    if rank == 0 and not args.no_roofline and conv_bound:
         fwd_f, train_f = conv_flops(plan)
         conv_ms, nlaunch = time_conv_kernels(plan, 5)
         ach = train_f / (conv_ms * 1e-3) / 1e12
@@ -453,6 +470,8 @@ def main():
                            'kernel': 'conv_gather(+row3, split-K) + conv_wgrad kernels (%d launches/step)' % nlaunch,
                            'algorithmic_gflop_per_image': round(train_f / B / 1e9, 2),
                            'conv_ms_per_step': round(conv_ms, 3)}
+    if args.arch.startswith('ksevendet'):          # (supplementary line of SURVEY 8 f-3: training step + roofline only)
+        args.no_infer = args.no_cpu_baseline = True
     if rank == 0 and world == 1 and not args.no_infer:
         inf = infer_bench(args, model, name, img, dev, emit=False)         # also inference img/s
         out['infer'] = {k: inf[k] for k in ('b1_decode_nms', 'heads_batched') if k in inf}

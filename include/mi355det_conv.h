@@ -45,7 +45,7 @@ typedef struct Mi355ConvProblem {
     const void* weight;  /* optional: THIS problem's weights (same [K][T][C] layout) and bias instead of the launch's:
                             the pyramid levels of an EfficientDet head conv share the conv but fold a BatchNorm per
                             level (efficientdet.py:335-353: bn_list[level][i]); NULL = the launch's weight / bias.
-                            bf16 gather launches without split-K only. */
+                            bf16 gather launches (split-K included: the finish pass applies the problem's bias). */
     const float* bias;   /* used with `weight` (may be NULL) */
 } Mi355ConvProblem;
 

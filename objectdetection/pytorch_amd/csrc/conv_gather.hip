@@ -907,8 +907,7 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         ProbDev& d = L.p[i];
         d.in = (const unsigned short*)s.in;  d.out = s.out;
         d.addend = (const unsigned short*)s.addend;  d.mask = (const unsigned short*)s.mask;
-        MI355_REQUIRE(!s.weight || (ksplit <= 1 && ((uintptr_t)s.weight & 15) == 0),
-                      "conv_gather: per-problem weights need 16-B alignment and are not available with split-K");
+        MI355_REQUIRE(!s.weight || ((uintptr_t)s.weight & 15) == 0, "conv_gather: per-problem weights need 16-B alignment");
         d.w = (const unsigned short*)(s.weight ? s.weight : in.weight);
         d.bias = s.weight ? s.bias : in.bias;
         d.N = s.N; d.H = s.H; d.W = s.W; d.C = s.C; d.P = s.P; d.Q = s.Q; d.sh = s.sh; d.sw = s.sw;
@@ -1010,7 +1009,7 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         for (int i = 0; i < in.nprob; ++i) {
             const long long n = (long long)fin[i].M * ((in.K + 7) / 8);
             hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, ws + off, ksplit,
-                               L.split_stride, fin[i], in.bias, in.K, in.act, in.out_f32, in.flags & 1);
+                               L.split_stride, fin[i], fin[i].bias, in.K, in.act, in.out_f32, in.flags & 1);
             off += (long long)fin[i].M * in.K;
         }
     }

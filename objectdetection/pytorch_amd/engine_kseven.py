@@ -11,6 +11,7 @@ reused as they are.  New here:
   keeps dgamma / dbeta per level.  BN layers left in train mode take the batch-statistics passes of `RetinaPlan`.
   The header convs (no BN) stay one grouped launch over the levels, writing fp32 [B, A, .] directly."""
 import ctypes
+import os
 
 import torch
 
@@ -137,11 +138,39 @@ class KSevenPlan(RetinaPlan):
         self.loss_ws_bytes = nb.value
         self.glosses = self.new((2,), torch.float32)
 
+    def _levels_grouped(self, layer):
+        """A tower conv over the pyramid levels as ONE grouped launch: the levels share the conv but fold their own
+        frozen BatchNorm, so every problem brings its own folded weights / bias (Mi355ConvProblem.weight).  Train-mode
+        BN (statistics passes per level) and the fp32-accurate mode keep one launch per level."""
+        return (self.prec != 'fp32' and self.deterministic and 2 <= len(layer) <= ops_conv.MAX_PROBLEMS and
+                not any(sp.bn_train for sp in layer) and os.environ.get('MI355_KS_GROUP', '1') != '0')
+
+    def _conv_levels(self, layer, xs, act):
+        s0 = layer[0]
+        outs, probs = [], []
+        for sp, x in zip(layer, xs):
+            N, H, W, C = x.shape
+            assert C == sp.Cpad and (sp.K, sp.Cpad, sp.T) == (s0.K, s0.Cpad, s0.T), sp.name
+            pt, pl, P, Q = sp.geometry(H, W)
+            out = self.new((N, P, Q, sp.Kpad), zero=sp.Kpad != sp.K)
+            pr = fwd_problem(x, out.data_ptr(), sp.R, sp.S, sp.stride, (pt, pl), K=sp.K, out_size=(P, Q),
+                             out_strides=(P * Q * sp.Kpad, Q * sp.Kpad, sp.Kpad))
+            pr.weight = sp.w_fwd.data_ptr()
+            pr.bias = 0 if sp.bias_tensor is None else sp.bias_tensor.data_ptr()
+            probs.append(pr)
+            outs.append(out)
+            self.fwd_launches.append((sp, [(N, P, Q)]))
+        self._gather(self.fwd_steps, probs, s0.w_fwd, s0.K, s0.T, bias=s0.bias_tensor, act=act)
+        return outs
+
     def _tower_fwd(self, tower):
-        """layers_num x [shared conv3x3 -> per-level BN -> ReLU] (simple_head.py:148-153): one launch per level."""
+        """layers_num x [shared conv3x3 -> per-level BN -> ReLU] (simple_head.py:148-153)."""
         xs, outs = self.levels, []
         for layer in tower:
-            xs = [self.conv(spec, x, ACT_RELU) for spec, x in zip(layer, xs)]
+            if self._levels_grouped(layer):
+                xs = self._conv_levels(layer, xs, ACT_RELU)
+            else:
+                xs = [self.conv(spec, x, ACT_RELU) for spec, x in zip(layer, xs)]
             outs.append(xs)
         return outs
 
@@ -183,6 +212,30 @@ class KSevenPlan(RetinaPlan):
         for li in range(len(tower) - 1, -1, -1):
             ins = acts[li - 1] if li > 0 else self.levels
             nxt = []
+            if self._levels_grouped(tower[li]):
+                # one weight-gradient launch (a workspace per level spec) and one data-gradient launch (per-level w_dgr)
+                group, dprobs = [], []
+                for lv, (spec, x, gy) in enumerate(zip(tower[li], ins, gys)):
+                    N, H, W, C = x.shape
+                    pt, pl, P, Q = spec.geometry(H, W)
+                    wp = fwd_problem(x, gy.data_ptr(), spec.R, spec.S, spec.stride, (pt, pl), K=spec.Kpad, out_size=(P, Q))
+                    group.append((wp, spec, N * P * Q))
+                    if li > 0:
+                        dx = self.new((N, H, W, spec.Cpad))
+                        nxt.append(dx)
+                        ps = ops_conv.dgrad_problems(gy, dx.data_ptr(), H, W, spec.Cpad, spec.R, spec.S, spec.stride, pt, mask=x)
+                    else:                               # into the pyramid-level gradient (second head: accumulate)
+                        gf = g_feat[lv]
+                        ps = ops_conv.dgrad_problems(gy, gf.data_ptr(), H, W, spec.Cpad, spec.R, spec.S, spec.stride, pt,
+                                                     addend=None if first else gf)
+                    assert len(ps) == 1
+                    ps[0].weight, ps[0].bias = spec.w_dgr.data_ptr(), 0
+                    dprobs.append(ps[0])
+                self._wgrad_multi(group)
+                s0 = tower[li][0]
+                self._gather(self.bwd_steps, dprobs, s0.w_dgr, s0.Cpad, s0.T)
+                gys = nxt
+                continue
             for lv, (spec, x, gy) in enumerate(zip(tower[li], ins, gys)):
                 if li > 0:
                     nxt.append(self.conv_bwd(spec, x, gy, mask=x))

@@ -244,6 +244,33 @@ def test_grouped_heads_shared_weights(dev):
     _close(G.reshape(K, 3, 3, C).permute(0, 3, 1, 2), refw, 2e-3)
 
 
+@pytest.mark.parametrize('ksplit', [1, 3])
+def test_grouped_launch_with_per_problem_weights(dev, ksplit):
+    """Mi355ConvProblem.weight / .bias: the pyramid levels of a conv that folds its own BatchNorm per level
+    (efficientdet.py:335-353, simple_head.py:148-153) in ONE launch == one launch per level, bit for bit; with and
+    without split-K (whose finish pass applies the problem's bias)."""
+    from objectdetection.pytorch_amd import ops_conv
+    N, C, K = 2, 128, 128
+    sizes = [(16, 20), (8, 10), (4, 5)]
+    xs, ws, bs, singles, probs, outs = [], [], [], [], [], []
+    for i, (h, ww) in enumerate(sizes):
+        xh = _mk((N, C, h, ww), 10 + i).permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+        w = _mk((K, C, 3, 3), 20 + i, scale=(2.0 / (C * 9)) ** 0.5)
+        _, w_fwd, _ = _shadow(w, dev)
+        b = _mk((K,), 30 + i).float().to(dev)
+        one = torch.empty((N, h, ww, K), dtype=torch.bfloat16, device=dev)
+        ops_conv.launch_gather([ops_conv.fwd_problem(xh, one.data_ptr(), 3, 3, 1, 1, K=K)], w_fwd, K, 9, one, bias=b,
+                               act=ops_conv.ACT_RELU, ksplit=ksplit)
+        out = torch.full((N, h, ww, K), float('nan'), dtype=torch.bfloat16, device=dev)
+        pr = ops_conv.fwd_problem(xh, out.data_ptr(), 3, 3, 1, 1, K=K)
+        pr.weight, pr.bias = w_fwd.data_ptr(), b.data_ptr()
+        xs.append(xh); ws.append(w_fwd); bs.append(b); singles.append(one); probs.append(pr); outs.append(out)
+    ops_conv.launch_gather(probs, ws[0], K, 9, outs[0], bias=None, act=ops_conv.ACT_RELU, ksplit=ksplit)
+    for one, out in zip(singles, outs):
+        assert torch.equal(one, out)
+    assert not torch.equal(outs[0][:, :4, :5], outs[2])          # (the levels really used different weights)
+
+
 def test_param_grads_with_frozen_bn(dev):
     """dW, dgamma, dbeta of conv -> BN(eval) from the raw wgrad + column sums."""
     from objectdetection.pytorch_amd import ops_conv
