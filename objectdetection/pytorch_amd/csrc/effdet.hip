@@ -207,6 +207,7 @@ struct DwTileLevel {
     unsigned short* out;
     const unsigned short* zin;
     int H, W, tilesX, tile_begin;
+    int P, Q;                      // output map (== H, W for the stride-1 "same" forms)
 };
 struct DwTileLaunch {
     DwTileLevel lv[MI355_DW_MAX_LEVELS];
@@ -220,10 +221,18 @@ struct DwTileLaunch {
     const float* nodew;
     int up1;
 };
-template <int K, bool FLIP, bool INSW = false, bool NODE = false>
+// S = 2 (forward only): the halo tile is kept as FOUR parity planes (input row parity, column parity), so that tap
+// (a, b) of output column tx reads cell tx + (b >> 1) of plane (a & 1, b & 1): consecutive lanes = consecutive cells, as
+// in the stride-1 form (a plain image would be read with stride 2: 2-way bank conflicts); swish once per loaded element
+// (the direct stride-2 kernel recomputes it (k / 2)^2 = 2.25 / 6.25 times: it is bound by v_exp / v_rcp, 85 us for the
+// 256^2 x 96 layer against a 50 us HBM floor).
+template <int K, bool FLIP, bool INSW = false, bool NODE = false, int S = 1>
 __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, const float* __restrict__ w_t,
                                                          const float* __restrict__ bias) {
-    constexpr int IH = DT_TH + K - 1, IW = DT_TW + K - 1, NPX = IH * IW;
+    constexpr int IH = (DT_TH - 1) * S + K, IW = (DT_TW - 1) * S + K;
+    constexpr int PH = (IH + S - 1) / S, PW = (IW + S - 1) / S;          // one parity plane (S == 1: the tile itself)
+    constexpr int NPX = S * S * PH * PW;
+    static_assert(!(FLIP || NODE) || S == 1, "stride 2: forward only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nc8 = L.nc8, C = L.C, pad_t = L.pad_t, pad_l = L.pad_l, accumulate = L.accumulate;
     s8v* tile = reinterpret_cast<s8v*>(smem);                              // [nc8][NPX]
@@ -237,17 +246,18 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, c
     const int tl = blockIdx.x - P.tile_begin;
     const int tyi = tl / P.tilesX, txi = tl - tyi * P.tilesX;
     const int q0 = txi * DT_TW, p0 = tyi * DT_TH;
-    const int H = P.H, W = P.W;
+    const int H = P.H, W = P.W, OP = P.P, OQ = P.Q;
     const unsigned short* __restrict__ in = P.in;
     unsigned short* __restrict__ out = P.out;
     const unsigned short* __restrict__ zin = P.zin;
     const int groups = (C >> 3) / nc8;
     const int n = blockIdx.y / groups, c8b = (blockIdx.y - n * groups) * nc8;
     // ---- input halo tile
-    for (int i = tid; i < NPX * nc8; i += 256) {
-        const int px = i / nc8, ch = i - px * nc8;
-        const int iy = px / IW, ix = px - iy * IW;
-        const int h = p0 - pad_t + iy, w = q0 - pad_l + ix;
+    for (int i = tid; i < IH * IW * nc8; i += 256) {
+        const int lin = i / nc8, ch = i - lin * nc8;
+        const int iy = lin / IW, ix = lin - iy * IW;
+        const int px = S == 1 ? lin : (((iy & 1) * 2 + (ix & 1)) * (PH * PW) + (iy >> 1) * PW + (ix >> 1));
+        const int h = p0 * S - pad_t + iy, w = q0 * S - pad_l + ix;
         s8v v = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
         if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
             const long long o = (((long long)n * H + h) * W + w) * C + (c8b + ch) * 8;
@@ -289,7 +299,8 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, c
         for (int a = 0; a < K; ++a)
 #pragma unroll
             for (int b = 0; b < K; ++b) {
-                const s8v v = tile[ch * NPX + (ty + a) * IW + tx + b];
+                const s8v v = S == 1 ? tile[ch * NPX + (ty + a) * IW + tx + b]
+                                     : tile[ch * NPX + ((a & 1) * 2 + (b & 1)) * (PH * PW) + (ty + (a >> 1)) * PW + tx + (b >> 1)];
                 const float4 w0 = *reinterpret_cast<const float4*>(wl + (a * K + b) * nc8 * 8 + ch * 8);
                 const float4 w1 = *reinterpret_cast<const float4*>(wl + (a * K + b) * nc8 * 8 + ch * 8 + 4);
                 acc[0] += bf16_to_f32((unsigned short)v[0]) * w0.x;  acc[1] += bf16_to_f32((unsigned short)v[1]) * w0.y;
@@ -314,8 +325,8 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, c
     for (int i = tid; i < 256 * nc8; i += 256) {
         const int px = i / nc8, ch = i - px * nc8;
         const int p = p0 + (px >> 5), q = q0 + (px & 31);
-        if (p >= H || q >= W) continue;
-        const long long off = (((long long)n * H + p) * W + q) * C + (c8b + ch) * 8;
+        if (p >= OP || q >= OQ) continue;
+        const long long off = (((long long)n * OP + p) * OQ + q) * C + (c8b + ch) * 8;
         if (FLIP) {
             const s8v sv = ot[ch * DT_OS + px];
             float v[8];
@@ -344,7 +355,7 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, c
 // output; data gradient: dx), aux = zin (data gradient only)
 struct DwNodeArgs { const void* in1; const void* in2; void* zout; const float* w; int up1; };
 
-template <int K, bool FLIP, bool INSW = false, bool NODE = false>
+template <int K, bool FLIP, bool INSW = false, bool NODE = false, int S = 1>
 static int launch_dw_tile(const Mi355DwLevel* levels, int nlevels, const float* w_t, const float* bias, int accumulate,
                           int N, int C, int pad_t, int pad_l, void* stream, const DwNodeArgs* node = nullptr) {
     const int c8n = C / 8;
@@ -355,28 +366,30 @@ static int launch_dw_tile(const Mi355DwLevel* levels, int nlevels, const float* 
         L.zout = (unsigned short*)node->zout;  L.nodew = node->w;  L.up1 = node->up1;
     }
     L.nlevels = nlevels; L.C = C; L.pad_t = pad_t; L.pad_l = pad_l; L.accumulate = accumulate;
-    L.nc8 = c8n % 4 == 0 ? 4 : (c8n % 2 == 0 ? 2 : 1);
+    L.nc8 = (S == 1 && c8n % 4 == 0) ? 4 : (c8n % 2 == 0 ? 2 : 1);        // stride 2: the halo tile is 4x the pixels
     long long tiles = 0;
     for (int i = 0; i < nlevels; ++i) {
         DwTileLevel& d = L.lv[i];
         d.in = (const unsigned short*)levels[i].x;  d.out = (unsigned short*)levels[i].dy;
         d.zin = (const unsigned short*)levels[i].aux;
         d.H = levels[i].H;  d.W = levels[i].W;
-        d.tilesX = (d.W + DT_TW - 1) / DT_TW;
+        d.P = S == 1 ? d.H : levels[i].P;  d.Q = S == 1 ? d.W : levels[i].Q;
+        d.tilesX = (d.Q + DT_TW - 1) / DT_TW;
         d.tile_begin = (int)tiles;
-        tiles += (long long)d.tilesX * ((d.H + DT_TH - 1) / DT_TH);
+        tiles += (long long)d.tilesX * ((d.P + DT_TH - 1) / DT_TH);
     }
     MI355_REQUIRE(tiles > 0 && tiles < 0x7fffffffLL && (long long)N * (c8n / L.nc8) <= 65535, "dw_tile: grid");
-    constexpr int NPX = (DT_TH + K - 1) * (DT_TW + K - 1);
+    constexpr int IH = (DT_TH - 1) * S + K, IW = (DT_TW - 1) * S + K;
+    constexpr int NPX = S * S * ((IH + S - 1) / S) * ((IW + S - 1) / S);
     static_assert(NPX >= DT_OS, "output staging must fit in the input tile");
     const size_t lds = (size_t)L.nc8 * NPX * 16 + (size_t)K * K * L.nc8 * 32;
     const dim3 grid((unsigned)tiles, (unsigned)(N * (c8n / L.nc8)));
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)dw_tile_s1_kernel<K, FLIP, INSW, NODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)dw_tile_s1_kernel<K, FLIP, INSW, NODE, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((dw_tile_s1_kernel<K, FLIP, INSW, NODE>), grid, dim3(256), lds, (hipStream_t)stream, L, w_t, bias);
+    hipLaunchKernelGGL((dw_tile_s1_kernel<K, FLIP, INSW, NODE, S>), grid, dim3(256), lds, (hipStream_t)stream, L, w_t, bias);
     return check_launch("dw_tile_s1_kernel");
 }
 
@@ -441,6 +454,17 @@ extern "C" int mi355_dwconv_fwd(const void* in, int in_swish, const float* w_t, 
                           : launch_dw_tile<5, false, true>(&lv, 1, w_t, bias, 0, N, C, pad_t, pad_l, stream);
         return k == 3 ? launch_dw_tile<3, false>(&lv, 1, w_t, bias, 0, N, C, pad_t, pad_l, stream)
                       : launch_dw_tile<5, false>(&lv, 1, w_t, bias, 0, N, C, pad_t, pad_l, stream);
+    }
+    if (stride == 2 && (k == 3 || k == 5) && Q >= 16 && P >= 8) {
+        // LDS-tiled with parity planes (TF-"same": the pad of the even-size maps is asymmetric, pad_t / pad_l as given)
+        Mi355DwLevel lv;
+        memset(&lv, 0, sizeof(lv));
+        lv.x = in; lv.dy = out; lv.H = H; lv.W = W; lv.P = P; lv.Q = Q;
+        if (in_swish)
+            return k == 3 ? launch_dw_tile<3, false, true, false, 2>(&lv, 1, w_t, bias, 0, N, C, pad_t, pad_l, stream)
+                          : launch_dw_tile<5, false, true, false, 2>(&lv, 1, w_t, bias, 0, N, C, pad_t, pad_l, stream);
+        return k == 3 ? launch_dw_tile<3, false, false, false, 2>(&lv, 1, w_t, bias, 0, N, C, pad_t, pad_l, stream)
+                      : launch_dw_tile<5, false, false, false, 2>(&lv, 1, w_t, bias, 0, N, C, pad_t, pad_l, stream);
     }
     if (stride == 1 && !in_swish && (k == 3 || k == 5) && P == H && Q == W) {
         const long long tot4 = (long long)N * P * ((Q + 3) / 4) * (C / 8);
