@@ -943,7 +943,10 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 template <int K, int S, bool INSW, int TW>
 __global__ __launch_bounds__(32 * K * (K == 3 ? 4 : 2), (S == 2 ? 3 : (K == 3 ? 5 : 4))) void dw_wgrad_tile_kernel(const DwWgLaunch L, float* __restrict__ slabs) {
     constexpr int TH = 256 / TW, RP = 32 / TW;              // RP tile rows side by side in the 32 pixel lanes
-    constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K, NPX = IH * IW, NOUT = 256;
+    constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K, NLIN = IH * IW, NOUT = 256;
+    // stride 2: the halo tile is kept as four parity planes (row parity, column parity) so that tap (a, b) of pixel
+    // lane pcol reads cell pcol + (b >> 1) of plane (a & 1, b & 1): consecutive lanes = consecutive cells
+    constexpr int PH = (IH + S - 1) / S, PW = (IW + S - 1) / S, NPX = S * S * PH * PW;
     constexpr int UJ = K == 3 ? 1 : 2;                      // unroll of the tile-row loop
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nc8 = L.nc8, C = L.C;
@@ -977,7 +980,7 @@ __global__ __launch_bounds__(32 * K * (K == 3 ? 4 : 2), (S == 2 ? 3 : (K == 3 ? 
         const unsigned short* gb = P.dy + (long long)n * P.P * P.Q * C + (c8b + sc) * 8;
         // every load of the tile is issued before the first use (a load -> swish -> LDS store loop is one HBM round
         // trip per cell: 22 us per tile)
-        constexpr int XI = (NPX + 32 * K - 1) / (32 * K), GI = (NOUT + 32 * K - 1) / (32 * K);   // sstep == 32 K
+        constexpr int XI = (NLIN + 32 * K - 1) / (32 * K), GI = (NOUT + 32 * K - 1) / (32 * K);  // sstep == 32 K
         u4v xr[XI], gr[GI];
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
@@ -985,7 +988,7 @@ __global__ __launch_bounds__(32 * K * (K == 3 ? 4 : 2), (S == 2 ? 3 : (K == 3 ? 
             const int iy = px / IW, ix = px - iy * IW;
             const int h = h0 + iy, w = w0 + ix;
             xr[i] = zero;
-            if (px < NPX && (unsigned)h < (unsigned)P.H && (unsigned)w < (unsigned)P.W)
+            if (px < NLIN && (unsigned)h < (unsigned)P.H && (unsigned)w < (unsigned)P.W)
                 xr[i] = *reinterpret_cast<const u4v*>(xb + ((long long)h * P.W + w) * C);
         }
 #pragma unroll
@@ -1006,7 +1009,11 @@ __global__ __launch_bounds__(32 * K * (K == 3 ? 4 : 2), (S == 2 ? 3 : (K == 3 ? 
                     v[e] = (unsigned)f32_to_bf16_rn(lo) | ((unsigned)f32_to_bf16_rn(hi) << 16);
                 }
             }
-            if (px < NPX) xt[sc * NPX + px] = v;
+            if (px < NLIN) {
+                const int iy = px / IW, ix = px - iy * IW;
+                const int cell = S == 1 ? px : (((iy & 1) * 2 + (ix & 1)) * (PH * PW) + (iy >> 1) * PW + (ix >> 1));
+                xt[sc * NPX + cell] = v;
+            }
         }
 #pragma unroll
         for (int i = 0; i < GI; ++i) {
@@ -1030,7 +1037,8 @@ __global__ __launch_bounds__(32 * K * (K == 3 ? 4 : 2), (S == 2 ? 3 : (K == 3 ? 
                 }
 #pragma unroll
                 for (int b = 0; b < K; ++b) {
-                    const u4v xv = xt[ch * NPX + (p * S + a) * IW + pcol * S + b];
+                    const u4v xv = S == 1 ? xt[ch * NPX + (p + a) * IW + pcol + b]
+                                          : xt[ch * NPX + ((a & 1) * 2 + (b & 1)) * (PH * PW) + (p + (a >> 1)) * PW + pcol + (b >> 1)];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         acc[b][2 * e] = dot2bf(xv[e], glo[e], acc[b][2 * e]);
@@ -1122,7 +1130,8 @@ extern "C" int mi355_dwconv_wgrad_nslabs(int N, int C, int k, int stride, int P,
 template <int K, int S, bool INSW, int TW>
 static void launch_dw_wgrad_tile(const DwWgLaunch& L, float* slabs, int nslabs, void* stream) {
     constexpr int TH = 256 / TW;
-    constexpr int NPX = ((TH - 1) * S + K) * ((TW - 1) * S + K);
+    constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+    constexpr int NPX = S * S * ((IH + S - 1) / S) * ((IW + S - 1) / S);
     const size_t lds = (size_t)L.nc8 * (NPX + 256) * 16;
     static bool attr = false;
     if (!attr) {
