@@ -27,6 +27,14 @@ int mi355_dw_prep_weight(const float* w, const float* scale, int C, int k, float
 int mi355_dwconv_fwd(const void* in, int in_swish, const float* w_t, const float* bias, void* out,
                      int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,
                      void* stream);
+/* The forward with the squeeze-excite pooling of its output (efficientnet.py:94-100: x = swish(bn1(depthwise_conv(x)));
+ * x_squeezed = adaptive_avg_pool2d(x, 1)) in the same launch: pool_partial [N][slabs][C] = per-tile partial means of
+ * swish(out), to be added in order by mi355_se_fc (slabs = mi355_dwconv_fwd_sepool_slabs; 0: this geometry is not
+ * served by the LDS-tiled kernel, use mi355_dwconv_fwd + mi355_se_pool). */
+int mi355_dwconv_fwd_sepool_slabs(int H, int W, int k, int stride, int P, int Q, int* slabs);
+int mi355_dwconv_fwd_sepool(const void* in, int in_swish, const float* w_t, const float* bias, void* out,
+                            float* pool_partial, int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l,
+                            int P, int Q, void* stream);
 /* dx = conv-transpose(dy) [* swish'(zin) if zin] [+ dx if accumulate] */
 int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, const void* zin, int N, int H, int W,
                        int C, int k, int stride, int pad_t, int pad_l, int P, int Q, int accumulate,

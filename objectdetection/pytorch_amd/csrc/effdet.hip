@@ -220,6 +220,11 @@ struct DwTileLaunch {
     unsigned short* zout;
     const float* nodew;
     int up1;
+    // squeeze-excite pooling of the OUTPUT (forward, one level): pool[(n * tiles + tile) * C + c] = pool_scale * sum over
+    // the tile's pixels of swish(out) — the slab partials mi355_se_fc adds in order (efficientnet.py:98-100:
+    // adaptive_avg_pool2d of swish(bn1(depthwise_conv(x)))); NULL = none
+    float* pool;
+    float pool_scale;
 };
 // S = 2 (forward only): the halo tile is kept as FOUR parity planes (input row parity, column parity), so that tap
 // (a, b) of output column tx reads cell tx + (b >> 1) of plane (a & 1, b & 1): consecutive lanes = consecutive cells, as
@@ -321,12 +326,18 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, c
     for (int ch = 0; ch < 4; ++ch)
         if (ch < nc8) ot[ch * DT_OS + tid] = res[ch];
     __syncthreads();
+    float psum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // SE pooling: this thread's pixels of chunk tid % nc8
     // ---- outputs: piece i = (pixel, chunk), a pixel's chunks contiguous in memory
     for (int i = tid; i < 256 * nc8; i += 256) {
         const int px = i / nc8, ch = i - px * nc8;
         const int p = p0 + (px >> 5), q = q0 + (px & 31);
         if (p >= OP || q >= OQ) continue;
         const long long off = (((long long)n * OP + p) * OQ + q) * C + (c8b + ch) * 8;
+        if (!FLIP && L.pool) {
+            const s8v sv = ot[ch * DT_OS + px];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) psum[e] += swishf(bf16_to_f32((unsigned short)sv[e]));
+        }
         if (FLIP) {
             const s8v sv = ot[ch * DT_OS + px];
             float v[8];
@@ -349,18 +360,45 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, c
             *reinterpret_cast<s8v*>(out + off) = ot[ch * DT_OS + px];
         }
     }
+    if (!FLIP && L.pool) {                                 // (uniform)
+        // threads with the same tid % nc8 hold the same chunk (256 % nc8 == 0): xor steps over the higher lane bits,
+        // then the four waves through LDS (the staging planes are dead by now)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);           // [4 waves][nc8][8]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = psum[e];
+            for (int o = 32; o >= nc8; o >>= 1) v += __shfl_xor(v, o, 64);
+            psum[e] = v;
+        }
+        const int lane = tid & 63, wv = tid >> 6;
+        if (lane < nc8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(wv * nc8 + lane) * 8 + e] = psum[e];
+        }
+        __syncthreads();
+        if (tid < nc8 * 8) {
+            const int ch = tid >> 3, e = tid & 7;
+            const float t = (red[(0 * nc8 + ch) * 8 + e] + red[(1 * nc8 + ch) * 8 + e]) +
+                            (red[(2 * nc8 + ch) * 8 + e] + red[(3 * nc8 + ch) * 8 + e]);
+            L.pool[((long long)n * gridDim.x + blockIdx.x) * C + (c8b + ch) * 8 + e] = t * L.pool_scale;
+        }
+    }
 }
 
 // levels[i]: x = the map the conv reads (forward: input; data gradient: dy), dy = the map it writes (forward:
 // output; data gradient: dx), aux = zin (data gradient only)
 struct DwNodeArgs { const void* in1; const void* in2; void* zout; const float* w; int up1; };
+struct DwPoolArgs { float* pool; float scale; };
 
 template <int K, bool FLIP, bool INSW = false, bool NODE = false, int S = 1>
 static int launch_dw_tile(const Mi355DwLevel* levels, int nlevels, const float* w_t, const float* bias, int accumulate,
-                          int N, int C, int pad_t, int pad_l, void* stream, const DwNodeArgs* node = nullptr) {
+                          int N, int C, int pad_t, int pad_l, void* stream, const DwNodeArgs* node = nullptr,
+                          const DwPoolArgs* pool = nullptr) {
     const int c8n = C / 8;
     DwTileLaunch L;
     memset(&L, 0, sizeof(L));
+    if (pool) { L.pool = pool->pool; L.pool_scale = pool->scale; }
     if (NODE) {
         L.in1 = (const unsigned short*)node->in1;  L.in2 = (const unsigned short*)node->in2;
         L.zout = (unsigned short*)node->zout;  L.nodew = node->w;  L.up1 = node->up1;
@@ -486,6 +524,38 @@ extern "C" int mi355_dwconv_fwd(const void* in, int in_swish, const float* w_t, 
                            (const unsigned short*)in, w_t, bias, (unsigned short*)out, N, H, W, C, k, stride,
                            pad_t, pad_l, P, Q);
     return check_launch("dwconv_fwd_kernel");
+}
+
+// mi355_dwconv_fwd + mi355_se_pool in one launch (the LDS-tiled forms only: k = 3 / 5, stride 1 "same" on maps >= 8 x 16,
+// stride 2 onto maps >= 8 x 16): `pool_partial` [N][slabs][C] receives per-tile partial means of swish(out), slabs =
+// mi355_dwconv_fwd_sepool_slabs(...) (0 = this geometry takes another kernel: call the two entry points).
+extern "C" int mi355_dwconv_fwd_sepool_slabs(int H, int W, int k, int stride, int P, int Q, int* slabs) {
+    MI355_REQUIRE(slabs && H > 0 && W > 0 && P > 0 && Q > 0, "dwconv_fwd_sepool_slabs: bad args");
+    const bool ok = (k == 3 || k == 5) && ((stride == 1 && P == H && Q == W && W >= 16 && H >= 8) ||
+                                           (stride == 2 && Q >= 16 && P >= 8));
+    *slabs = ok ? ((Q + DT_TW - 1) / DT_TW) * ((P + DT_TH - 1) / DT_TH) : 0;
+    return MI355_OK;
+}
+
+extern "C" int mi355_dwconv_fwd_sepool(const void* in, int in_swish, const float* w_t, const float* bias, void* out,
+                                       float* pool_partial, int N, int H, int W, int C, int k, int stride, int pad_t,
+                                       int pad_l, int P, int Q, void* stream) {
+    int slabs = 0;
+    MI355_REQUIRE(in && w_t && out && pool_partial && N > 0 && C > 0 && C % 8 == 0, "dwconv_fwd_sepool: bad args");
+    mi355_dwconv_fwd_sepool_slabs(H, W, k, stride, P, Q, &slabs);
+    MI355_REQUIRE(slabs > 0, "dwconv_fwd_sepool: geometry not served by the tiled kernel (see mi355_dwconv_fwd_sepool_slabs)");
+    Mi355DwLevel lv;
+    memset(&lv, 0, sizeof(lv));
+    lv.x = in; lv.dy = out; lv.H = H; lv.W = W; lv.P = P; lv.Q = Q;
+    const DwPoolArgs pool = {pool_partial, 1.0f / (float)((long long)P * Q)};
+#define MI355_DWP(KK, SW, SS) launch_dw_tile<KK, false, SW, false, SS>(&lv, 1, w_t, bias, 0, N, C, pad_t, pad_l, stream, nullptr, &pool)
+    if (stride == 1) {
+        if (in_swish) return k == 3 ? MI355_DWP(3, true, 1) : MI355_DWP(5, true, 1);
+        return k == 3 ? MI355_DWP(3, false, 1) : MI355_DWP(5, false, 1);
+    }
+    if (in_swish) return k == 3 ? MI355_DWP(3, true, 2) : MI355_DWP(5, true, 2);
+    return k == 3 ? MI355_DWP(3, false, 2) : MI355_DWP(5, false, 2);
+#undef MI355_DWP
 }
 
 template <typename T>
@@ -1412,12 +1482,34 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ pa
     float* s_pool = sm;
     float* s_r = sm + C;
     const int n = blockIdx.x, tid = threadIdx.x;
-    for (int c = tid; c < C; c += 256) {
-        float t = 0.0f;
+    {
+        // the slab partials in a fixed order; narrow layers (C <= 128: up to 256 slabs from the depthwise forward's
+        // tiles) split the slab range over the idle threads and combine the parts in order
+        __shared__ float s_sp[256];
+        int cl = 256, parts = 1;
+        while (parts < 16 && (cl >> 1) >= C) { cl >>= 1; parts <<= 1; }       // cl * parts == 256, cl >= C when parts > 1
+        const int pi = tid / cl, c0 = tid - pi * cl;
+        const int lo = (int)((long long)slabs * pi / parts), hi = (int)((long long)slabs * (pi + 1) / parts);
+        for (int c = c0; c < C; c += cl) {
+            float t = 0.0f;
 #pragma unroll 8
-        for (int sl = 0; sl < slabs; ++sl) t += part[((long long)n * slabs + sl) * C + c];   // fixed order
-        s_pool[c] = t;
-        pool[(long long)n * C + c] = t;
+            for (int sl = lo; sl < hi; ++sl) t += part[((long long)n * slabs + sl) * C + c];
+            if (parts == 1) {
+                s_pool[c] = t;
+                pool[(long long)n * C + c] = t;
+            } else {
+                s_sp[pi * cl + c] = t;
+            }
+        }
+        if (parts > 1) {                                   // (uniform)
+            __syncthreads();
+            if (tid < C) {
+                float t = s_sp[tid];
+                for (int q = 1; q < parts; ++q) t += s_sp[q * cl + tid];
+                s_pool[tid] = t;
+                pool[(long long)n * C + tid] = t;
+            }
+        }
     }
     __syncthreads();
     // squeeze: one wave per reduced channel j, lanes stride over c (coalesced rows of w1), shuffle reduction

@@ -217,9 +217,11 @@ class EffDetPlan(RetinaPlan):
         self.tape.append(bwd)
         return out
 
-    def dw_op(self, spec, x, x_swish, emit_fwd=True):
+    def dw_op(self, spec, x, x_swish, emit_fwd=True, se_pool=False):
         """(emit_fwd=False: the caller launches the forward itself, fused with the producer of x; everything else —
-        output buffer, slab rows, taped backward — is registered here.)"""
+        output buffer, slab rows, taped backward — is registered here.  se_pool=True: when the geometry is served by
+        the LDS-tiled forward, the squeeze-excite pooling of the output rides in the same launch and
+        self._last_se_pool = (partials [N][slabs][C], slabs) is set for se_op; otherwise it is None.)"""
         N, H, W, C = x.shape
         pt, P = same_pad(H, spec.k, spec.stride)
         pl, Q = same_pad(W, spec.k, spec.stride)
@@ -230,6 +232,17 @@ class EffDetPlan(RetinaPlan):
         # LDS-tiled forward, once per kernel row in the sliding-window weight gradient; v_exp + v_rcp, rounded to
         # bf16 exactly like a materialised swish(z)): no elementwise pass, no second copy of the activation
         xs, insw = x, int(bool(x_swish))
+        self._last_se_pool = None
+        if se_pool and emit_fwd and self.prec != 'fp32' and os.environ.get('MI355_EFF_FUSE_SEPOOL', '1') != '0':
+            ns = ctypes.c_int()
+            _lib.call('mi355_dwconv_fwd_sepool_slabs', c_int(H), c_int(W), c_int(spec.k), c_int(spec.stride), c_int(P),
+                      c_int(Q), ctypes.byref(ns))
+            if ns.value > 0:
+                part = self.new((N, ns.value, C), torch.float32)
+                self._last_se_pool = (part, ns.value)
+                self._step(self.fwd_steps, 'mi355_dwconv_fwd_sepool', ptr(xs), c_int(insw), ptr(spec.w_t),
+                           ptr(spec.shift), ptr(out), ptr(part), *geo)
+                emit_fwd = False
         if emit_fwd:
             self._step(self.fwd_steps, 'mi355_dwconv_fwd', ptr(xs), c_int(insw), ptr(spec.w_t), ptr(spec.shift),
                        ptr(out), *geo)
@@ -354,21 +367,23 @@ class EffDetPlan(RetinaPlan):
         self.tape.append(bwd)
         return outs
 
-    def se_op(self, spec, z):
+    def se_op(self, spec, z, pooled=None):
+        """pooled = (partials, slabs) when the producing depthwise conv already stored the pooling partials."""
         N, H, W, C = z.shape
         HW = H * W
         ns = ctypes.c_int()
         _lib.call('mi355_se_slabs', c_int(N), c_int(HW), ctypes.byref(ns))
-        slabs = ns.value
-        part = self.new((N, slabs, C), torch.float32)
+        slabs = ns.value                                    # (of the backward's reduction; the forward's may differ)
+        part, fslabs = pooled if pooled is not None else (self.new((N, slabs, C), torch.float32), slabs)
         pool = self.new((N, C), torch.float32)
         rpre = self.new((N, spec.Cse), torch.float32)
         gate = self.new((N, C), torch.float32)
         u = self.new(tuple(z.shape))
         w1, b1, w2, b2 = spec.reduce.weight, spec.reduce.bias, spec.expand.weight, spec.expand.bias
         dims = (c_int(N), c_int(HW), c_int(C))
-        self._step(self.fwd_steps, 'mi355_se_pool', ptr(z), c_int(1), ptr(part), *dims)
-        self._step(self.fwd_steps, 'mi355_se_fc', ptr(part), c_int(slabs), ptr(pool), ptr(w1), ptr(b1), ptr(w2),
+        if pooled is None:
+            self._step(self.fwd_steps, 'mi355_se_pool', ptr(z), c_int(1), ptr(part), *dims)
+        self._step(self.fwd_steps, 'mi355_se_fc', ptr(part), c_int(fslabs), ptr(pool), ptr(w1), ptr(b1), ptr(w2),
                    ptr(b2), ptr(rpre), ptr(gate), c_int(N), c_int(C), c_int(spec.Cse))
         self._step(self.fwd_steps, 'mi355_se_scale', ptr(z), ptr(gate), ptr(u), *dims)
 
@@ -547,8 +562,8 @@ class EffDetPlan(RetinaPlan):
                 dw_in, dw_sw = self.pw_op(rec['expand'], inp), True
             else:
                 dw_in, dw_sw = inp, cur_sw
-            z1 = self.dw_op(rec['dw'], dw_in, dw_sw)
-            u = self.se_op(rec['se'], z1)
+            z1 = self.dw_op(rec['dw'], dw_in, dw_sw, se_pool=True)
+            u = self.se_op(rec['se'], z1, self._last_se_pool)
             rate = getattr(eff_gp, 'drop_connect_rate', None)
             rate = rate * float(i) / nblk if rate else 0.0                 # efficientdet.py:421-423
             if rec['skip'] and self.drop_connect and rate:

@@ -136,6 +136,35 @@ def test_maxpool_same_zero_padding():
         _close(gin.permute(0, 3, 1, 2), x.grad, 1e-2)
 
 
+@pytest.mark.parametrize('N,H,W,C,k,s', [(2, 16, 40, 32, 3, 1), (2, 9, 70, 24, 5, 1), (1, 40, 132, 16, 3, 2), (2, 32, 70, 48, 5, 2)])
+def test_depthwise_forward_with_se_pooling(N, H, W, C, k, s):
+    """mi355_dwconv_fwd_sepool: the same output as mi355_dwconv_fwd, bit for bit, and per-tile partial means of
+    swish(out) that add up to mi355_se_pool's."""
+    from objectdetection.pytorch_amd import ops_effdet as E
+    from objectdetection.pytorch_amd._lib import call, ptr, c_int, stream_of
+    x = _nhwc(_mk((N, C, H, W), 1))
+    w_t = (torch.randn((k * k, C), generator=torch.Generator().manual_seed(1)) * 0.3).to(DEV)
+    bias = (torch.randn(C, generator=torch.Generator().manual_seed(2)) * 0.1).to(DEV)
+    ref = E.dwconv_fwd(x, True, w_t, bias, k, s)
+    pt, P = E.same_pad(H, k, s)
+    pl, Q = E.same_pad(W, k, s)
+    ns = ctypes.c_int()
+    call('mi355_dwconv_fwd_sepool_slabs', c_int(H), c_int(W), c_int(k), c_int(s), c_int(P), c_int(Q), ctypes.byref(ns))
+    assert ns.value > 0
+    out = torch.full_like(ref, float('nan'))
+    part = torch.full((N, ns.value, C), float('nan'), device=DEV)
+    call('mi355_dwconv_fwd_sepool', ptr(x), c_int(1), ptr(w_t), ptr(bias), ptr(out), ptr(part), c_int(N), c_int(H), c_int(W),
+         c_int(C), c_int(k), c_int(s), c_int(pt), c_int(pl), c_int(P), c_int(Q), stream_of(x))
+    assert torch.equal(out, ref)
+    pooled = R.swish(ref.float()).mean((1, 2))
+    _close(part.sum(1), pooled.cpu(), 2e-3)
+    ns2 = ctypes.c_int()
+    call('mi355_se_slabs', c_int(N), c_int(P * Q), ctypes.byref(ns2))
+    part2 = torch.empty((N, ns2.value, C), device=DEV)
+    call('mi355_se_pool', ptr(ref), c_int(1), ptr(part2), c_int(N), c_int(P * Q), c_int(C), stream_of(x))
+    _close(part.sum(1), part2.sum(1).cpu(), 1e-5)
+
+
 def test_squeeze_excite_fwd_bwd():
     from objectdetection.pytorch_amd._lib import call, ptr, c_int, stream_of
     N, C, Cse, H, W = 3, 96, 4, 12, 10
