@@ -39,6 +39,12 @@ int mi355_dwconv_fwd_sepool(const void* in, int in_swish, const float* w_t, cons
 int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, const void* zin, int N, int H, int W,
                        int C, int k, int stride, int pad_t, int pad_l, int P, int Q, int accumulate,
                        void* stream);
+/* mi355_se_bwd_apply followed by mi355_dwconv_dgrad in ONE launch (stride 1, "same", k = 3 / 5, maps >= 8 x 16): gz (stored:
+ * the weight gradient reads it) is built while the data gradient's halo tile is staged; bit-identical to the two launches.
+ * (efficientnet.py:94-104 backward: the gradient of swish(bn1(depthwise_conv(x))) * sigmoid(se(...)) w.r.t. the conv output) */
+int mi355_dwconv_dgrad_seapply(const void* gu, const void* z, const float* gate, const float* gpool, void* gz,
+                               const float* w_t, void* dx, const void* zin, int N, int H, int W, int C, int k,
+                               int accumulate, void* stream);
 /* dw_t[t][c] += sum_m f(x)[m@t][c] * dy[m][c];  colsum[c] += sum_m dy[m][c] (may be NULL) */
 int mi355_dwconv_wgrad(const void* x, int in_swish, const void* dy, float* dw_t, float* colsum, int N,
                        int H, int W, int C, int k, int stride, int pad_t, int pad_l, int P, int Q,

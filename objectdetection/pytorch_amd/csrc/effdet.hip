@@ -60,6 +60,10 @@ template <> struct Act<float> {
     static __device__ __forceinline__ float dsw(float x) { return dswishf_exact(x); }
 };
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+// squeeze-excite backward, d/dz of gate * swish(z) with the pooled term: one explicit fma wherever it is evaluated
+__device__ __forceinline__ float se_apply_mix(float gu, float gate, float gpool, float inv_hw, float dsw) {
+    return fmaf(gu, gate, gpool * inv_hw) * dsw;
+}
 // BiFPN fast-attention mix, one explicit fma chain wherever a node is evaluated (bit-identical z in every kernel)
 __device__ __forceinline__ float node_mix(float w0, float a, float w1, float b, float w2, float c) {
     return fmaf(w2, c, fmaf(w1, b, w0 * a));
@@ -225,13 +229,21 @@ struct DwTileLaunch {
     // adaptive_avg_pool2d of swish(bn1(depthwise_conv(x)))); NULL = none
     float* pool;
     float pool_scale;
+    // SEAPPLY form (data gradient, one level): the conv's input dy is the squeeze-excite backward
+    // gz = (gu * gate[n][c] + gpool[n][c] / HW) * swish'(z) (mi355_se_bwd_apply), built while the halo tile is staged from
+    // `in` = gu and stored to `ap_gz` by the tile that owns the pixel (the weight gradient reads it)
+    const unsigned short* ap_z;
+    const float* ap_gate;
+    const float* ap_gpool;
+    unsigned short* ap_gz;
+    float ap_inv;
 };
 // S = 2 (forward only): the halo tile is kept as FOUR parity planes (input row parity, column parity), so that tap
 // (a, b) of output column tx reads cell tx + (b >> 1) of plane (a & 1, b & 1): consecutive lanes = consecutive cells, as
 // in the stride-1 form (a plain image would be read with stride 2: 2-way bank conflicts); swish once per loaded element
 // (the direct stride-2 kernel recomputes it (k / 2)^2 = 2.25 / 6.25 times: it is bound by v_exp / v_rcp, 85 us for the
 // 256^2 x 96 layer against a 50 us HBM floor).
-template <int K, bool FLIP, bool INSW = false, bool NODE = false, int S = 1>
+template <int K, bool FLIP, bool INSW = false, bool NODE = false, int S = 1, bool SEAPPLY = false>
 __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, const float* __restrict__ w_t,
                                                          const float* __restrict__ bias) {
     constexpr int IH = (DT_TH - 1) * S + K, IW = (DT_TW - 1) * S + K;
@@ -279,6 +291,17 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, c
                                                           w2, bf16_to_f32((unsigned short)c[e])));
                 if (iy >= pad_t && iy < pad_t + DT_TH && ix >= pad_l && ix < pad_l + DT_TW)
                     *reinterpret_cast<s8v*>(L.zout + o) = v;   // this tile's own output pixels
+            }
+            if (SEAPPLY) {
+                const s8v zc = *reinterpret_cast<const s8v*>(L.ap_z + o);
+                const float* ga = L.ap_gate + (long long)n * C + (c8b + ch) * 8;
+                const float* gp = L.ap_gpool + (long long)n * C + (c8b + ch) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)                // (same expression as se_bwd_apply_kernel: bit-identical gz)
+                    v[e] = (short)f32_to_bf16_rn(se_apply_mix(bf16_to_f32((unsigned short)v[e]), ga[e], gp[e], L.ap_inv,
+                                                              dswishf(bf16_to_f32((unsigned short)zc[e]))));
+                if (iy >= pad_t && iy < pad_t + DT_TH && ix >= pad_l && ix < pad_l + DT_TW)
+                    *reinterpret_cast<s8v*>(L.ap_gz + o) = v;
             }
         }
         if (INSW) {                                        // input stored as pre-activation z: swish once per loaded
@@ -390,15 +413,20 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, c
 // output; data gradient: dx), aux = zin (data gradient only)
 struct DwNodeArgs { const void* in1; const void* in2; void* zout; const float* w; int up1; };
 struct DwPoolArgs { float* pool; float scale; };
+struct DwApplyArgs { const void* z; const float* gate; const float* gpool; void* gz; float inv; };
 
-template <int K, bool FLIP, bool INSW = false, bool NODE = false, int S = 1>
+template <int K, bool FLIP, bool INSW = false, bool NODE = false, int S = 1, bool SEAPPLY = false>
 static int launch_dw_tile(const Mi355DwLevel* levels, int nlevels, const float* w_t, const float* bias, int accumulate,
                           int N, int C, int pad_t, int pad_l, void* stream, const DwNodeArgs* node = nullptr,
-                          const DwPoolArgs* pool = nullptr) {
+                          const DwPoolArgs* pool = nullptr, const DwApplyArgs* apply = nullptr) {
     const int c8n = C / 8;
     DwTileLaunch L;
     memset(&L, 0, sizeof(L));
     if (pool) { L.pool = pool->pool; L.pool_scale = pool->scale; }
+    if (SEAPPLY) {
+        L.ap_z = (const unsigned short*)apply->z;  L.ap_gate = apply->gate;  L.ap_gpool = apply->gpool;
+        L.ap_gz = (unsigned short*)apply->gz;  L.ap_inv = apply->inv;
+    }
     if (NODE) {
         L.in1 = (const unsigned short*)node->in1;  L.in2 = (const unsigned short*)node->in2;
         L.zout = (unsigned short*)node->zout;  L.nodew = node->w;  L.up1 = node->up1;
@@ -424,10 +452,10 @@ static int launch_dw_tile(const Mi355DwLevel* levels, int nlevels, const float* 
     const dim3 grid((unsigned)tiles, (unsigned)(N * (c8n / L.nc8)));
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)dw_tile_s1_kernel<K, FLIP, INSW, NODE, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)dw_tile_s1_kernel<K, FLIP, INSW, NODE, S, SEAPPLY>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((dw_tile_s1_kernel<K, FLIP, INSW, NODE, S>), grid, dim3(256), lds, (hipStream_t)stream, L, w_t, bias);
+    hipLaunchKernelGGL((dw_tile_s1_kernel<K, FLIP, INSW, NODE, S, SEAPPLY>), grid, dim3(256), lds, (hipStream_t)stream, L, w_t, bias);
     return check_launch("dw_tile_s1_kernel");
 }
 
@@ -708,6 +736,23 @@ extern "C" int mi355_dwconv_dgrad(const void* dy, const float* w_t, void* dx, co
                        (const unsigned short*)dy, w_t, (unsigned short*)dx, (const unsigned short*)zin, N, H, W, C,
                        k, stride, pad_t, pad_l, P, Q, accumulate);
     return check_launch("dwconv_dgrad_kernel");
+}
+
+// mi355_se_bwd_apply + mi355_dwconv_dgrad (stride 1, "same", k = 3 / 5, maps >= 8 x 16) in one launch: the depthwise
+// conv's output gradient gz = (gu * gate + gpool / HW) * swish'(z) is built while the halo tile is staged and stored
+// (the weight gradient reads it); dx = conv-transpose(gz) [* swish'(zin)] [+ dx]; bit-identical to the pair.
+extern "C" int mi355_dwconv_dgrad_seapply(const void* gu, const void* z, const float* gate, const float* gpool, void* gz,
+                                          const float* w_t, void* dx, const void* zin, int N, int H, int W, int C, int k,
+                                          int accumulate, void* stream) {
+    MI355_REQUIRE(gu && z && gate && gpool && gz && w_t && dx && N > 0 && C > 0 && C % 8 == 0 && (k == 3 || k == 5) &&
+                  W >= 16 && H >= 8, "dwconv_dgrad_seapply: stride-1 'same' 3x3 / 5x5 on maps >= 8 x 16 only");
+    Mi355DwLevel lv;
+    memset(&lv, 0, sizeof(lv));
+    lv.x = gu; lv.dy = dx; lv.aux = zin; lv.H = H; lv.W = W;
+    const DwApplyArgs ap = {z, gate, gpool, gz, 1.0f / (float)((long long)H * W)};
+    const int p = k - 1 - (k - 1) / 2;
+    return k == 3 ? launch_dw_tile<3, true, false, false, 1, true>(&lv, 1, w_t, nullptr, accumulate, N, C, p, p, stream, nullptr, nullptr, &ap)
+                  : launch_dw_tile<5, true, false, false, 1, true>(&lv, 1, w_t, nullptr, accumulate, N, C, p, p, stream, nullptr, nullptr, &ap);
 }
 
 // block = 32 (tap, 8-channel chunk) items x 8 pixel lanes over a chunk of output rows; the pixel
@@ -1783,7 +1828,7 @@ __global__ void se_bwd_apply_kernel(const T* __restrict__ gu, const T* __restric
     const float* gp = gpool + n * C + c8 * 8;
     const float inv = 1.0f / (float)HW;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = (g[e] * ga[e] + gp[e] * inv) * Act<T>::dsw(v[e]);
+    for (int e = 0; e < 8; ++e) g[e] = se_apply_mix(g[e], ga[e], gp[e], inv, Act<T>::dsw(v[e]));
     store8(gz + t * 8, g);
 }
 

@@ -254,10 +254,26 @@ class EffDetPlan(RetinaPlan):
             slab_base = spec.nslabs
             spec.nslabs += ops_effdet.dwconv_wgrad_nslabs(N, C, spec.k, spec.stride, P, Q)
 
+        # squeeze-excite backward inside this conv's data-gradient launch (the MBConv depthwise convs whose stride-1
+        # "same" data gradient takes the LDS-tiled kernel): se_op's backward leaves (gu, gate, gpool) here instead of
+        # launching mi355_se_bwd_apply
+        fuse_apply = (se_pool and self.prec != 'fp32' and spec.stride == 1 and spec.k in (3, 5) and W >= 16 and H >= 8 and
+                      os.environ.get('MI355_EFF_FUSE_SEAPPLY', '1') != '0')
+        if fuse_apply:
+            self._se_apply_in_dgrad[id(out)] = None
+
         def bwd():
             if not self.has_grad(out):
                 return
             dy = self.grad(out)
+            pend = self._se_apply_in_dgrad.get(id(out)) if fuse_apply else None
+            if pend is not None:                            # data gradient first: it also stores dy for the weight gradient
+                gu, gate, gpool = pend
+                dx = self.grad(x)
+                acc = not self.first_write(x)
+                self._step(self.bwd_steps, 'mi355_dwconv_dgrad_seapply', ptr(gu), ptr(out), ptr(gate), ptr(gpool), ptr(dy),
+                           ptr(spec.w_t), ptr(dx), ptr(x if x_swish else None), c_int(N), c_int(H), c_int(W), c_int(C),
+                           c_int(spec.k), c_int(int(acc)))
             if slab_base is not None:
                 row = (spec.T + 1) * C
                 if spec.slabs is None:                      # all forward launches of the layer are known by now
@@ -269,10 +285,11 @@ class EffDetPlan(RetinaPlan):
                 self._dw_atomic = True                      # dw_scratch is accumulated into: cleared every step
                 self._step(self.bwd_steps, 'mi355_dwconv_wgrad', ptr(xs), c_int(insw), ptr(dy), ptr(spec.G_t),
                            ptr(spec.colsum if spec.bn is not None else None), *geo)
-            dx = self.grad(x)
-            acc = not self.first_write(x)
-            self._step(self.bwd_steps, 'mi355_dwconv_dgrad', ptr(dy), ptr(spec.w_t), ptr(dx),
-                       ptr(x if x_swish else None), *(geo + (c_int(int(acc)),)))
+            if pend is None:
+                dx = self.grad(x)
+                acc = not self.first_write(x)
+                self._step(self.bwd_steps, 'mi355_dwconv_dgrad', ptr(dy), ptr(spec.w_t), ptr(dx),
+                           ptr(x if x_swish else None), *(geo + (c_int(int(acc)),)))
         self.tape.append(bwd)
         return out
 
@@ -403,7 +420,11 @@ class EffDetPlan(RetinaPlan):
                        c_int(slabs), ptr(de), ptr(dr), ptr(gpool), c_int(N), c_int(C), c_int(spec.Cse))
             gz = self.grad(z)
             assert self.first_write(z)
-            self._step(self.bwd_steps, 'mi355_se_bwd_apply', ptr(gu), ptr(z), ptr(gate), ptr(gpool), ptr(gz), *dims)
+            if id(z) in self._se_apply_in_dgrad:
+                # the depthwise conv that produced z builds gz inside its data-gradient launch (dw_op's backward runs next)
+                self._se_apply_in_dgrad[id(z)] = (gu, gate, gpool)
+            else:
+                self._step(self.bwd_steps, 'mi355_se_bwd_apply', ptr(gu), ptr(z), ptr(gate), ptr(gpool), ptr(gz), *dims)
         self.tape.append(bwd)
         return u
 
@@ -537,6 +558,7 @@ class EffDetPlan(RetinaPlan):
         m = self.model
         self._gbuf, self._gwritten, self.tape = {}, set(), []
         self._se_bwd, self._fusion_bwd = [], []
+        self._se_apply_in_dgrad = {}
         nse = sum(B * s.C for s in self.se_specs)
         self._zf = self.new((nse + 64,), torch.float32, zero=True)
         self._zb = self.new((nse + 64 * 8 * len(self.cells) + 64,), torch.float32, zero=True)

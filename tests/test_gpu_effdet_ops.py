@@ -165,6 +165,27 @@ def test_depthwise_forward_with_se_pooling(N, H, W, C, k, s):
     _close(part.sum(1), part2.sum(1).cpu(), 1e-5)
 
 
+@pytest.mark.parametrize('N,H,W,C,k,acc', [(2, 16, 40, 32, 3, False), (2, 9, 70, 24, 5, True)])
+def test_se_backward_apply_inside_the_depthwise_data_gradient(N, H, W, C, k, acc):
+    """mi355_dwconv_dgrad_seapply == mi355_se_bwd_apply then mi355_dwconv_dgrad, gz included, bit for bit."""
+    from objectdetection.pytorch_amd import ops_effdet as E
+    from objectdetection.pytorch_amd._lib import call, ptr, c_int, stream_of
+    gu, z, zin = _nhwc(_mk((N, C, H, W), 1)), _nhwc(_mk((N, C, H, W), 2)), _nhwc(_mk((N, C, H, W), 3))
+    gate = torch.rand((N, C), generator=torch.Generator().manual_seed(4)).to(DEV)
+    gpool = (torch.randn((N, C), generator=torch.Generator().manual_seed(5)) * 3.0).to(DEV)
+    w_t = (torch.randn((k * k, C), generator=torch.Generator().manual_seed(6)) * 0.3).to(DEV)
+    base = _nhwc(_mk((N, C, H, W), 7))
+    gz_ref = torch.empty_like(gu)
+    call('mi355_se_bwd_apply', ptr(gu), ptr(z), ptr(gate), ptr(gpool), ptr(gz_ref), c_int(N), c_int(H * W), c_int(C), stream_of(gu))
+    dx_ref = E.dwconv_dgrad(gz_ref, w_t, tuple(gu.shape), k, 1, zin=zin, dx=base.clone(), accumulate=acc)
+    gz = torch.full_like(gu, float('nan'))
+    dx = base.clone()
+    call('mi355_dwconv_dgrad_seapply', ptr(gu), ptr(z), ptr(gate), ptr(gpool), ptr(gz), ptr(w_t), ptr(dx), ptr(zin), c_int(N),
+         c_int(H), c_int(W), c_int(C), c_int(k), c_int(int(acc)), stream_of(gu))
+    assert torch.equal(gz, gz_ref)
+    assert torch.equal(dx, dx_ref)
+
+
 def test_squeeze_excite_fwd_bwd():
     from objectdetection.pytorch_amd._lib import call, ptr, c_int, stream_of
     N, C, Cse, H, W = 3, 96, 4, 12, 10
