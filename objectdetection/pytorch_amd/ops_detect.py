@@ -151,8 +151,9 @@ def score_filter(score, thr):
     return idx[:int(cnt.item())]          # host sync, as the reference's boolean indexing
 
 
-NMS_HEAD = 4096          # candidates of the first matrix pass of the two-phase schedule
-NMS_DIRECT_MAX = 8192    # up to here one matrix pass over all candidates
+import os as _os
+NMS_HEAD = int(_os.environ.get('MI355_NMS_HEAD', '4096'))               # candidates of a round's matrix pass (two-phase schedule)
+NMS_DIRECT_MAX = int(_os.environ.get('MI355_NMS_DIRECT_MAX', '8192'))   # up to here one matrix pass over all candidates
 
 
 def _aligned(nbytes, device):

@@ -89,6 +89,33 @@ def test_effdet_vs_reference_golden(golden_dir, tag):
     print(tag, 'worst sampled-grad cosine', worst)
 
 
+@pytest.mark.parametrize('case', ['ragged', 'empty'])
+def test_effdet_ragged_and_empty_annotations(golden_dir, case):
+    """The collater's -1 padding rows (datasettool/dataloader.py:655-691) through the EfficientDet plan: an image without a
+    single box beside one with boxes, and a batch without any (losses.py:50-60: both losses 0, no gradient), against the
+    oracle in the fp32-accurate mode."""
+    g, model, img, ann, sd, coef, nc = _build('effdet_d0_128', golden_dir)
+    model.precision = 'fp32'
+    ann = ann.clone()
+    if case == 'ragged':
+        ann[0] = -1.0                                       # image 0: only padding rows
+        ann[1, 3:] = -1.0                                   # image 1: three boxes, then padding
+    else:
+        ann[:] = -1.0
+    cl, rl = model(img, ann)
+    p = {k: torch.from_numpy(v).clone() for k, v in sd.items()}
+    clo, rlo = ref_effdet.efficientdet_loss(p, img.cpu(), ann.cpu(), coef, nc)
+    if case == 'empty':
+        assert float(cl) == 0.0 and float(rl) == 0.0 and float(clo) == 0.0 and float(rlo) == 0.0
+    else:
+        np.testing.assert_allclose(cl.item(), clo.mean().item(), rtol=1e-4)
+        np.testing.assert_allclose(rl.item(), rlo.mean().item(), rtol=1e-4)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    gn = np.sqrt(sum(float((q.grad.double() ** 2).sum()) for q in model.parameters() if q.grad is not None))
+    assert np.isfinite(gn) and ((gn == 0.0) if case == 'empty' else (gn > 0.0))
+
+
 def test_effdet_decode_tail(golden_dir):
     g, model, img, ann, sd, coef, nc = _build('effdet_d2_128x256', golden_dir)
     model.eval()
