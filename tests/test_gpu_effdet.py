@@ -116,6 +116,25 @@ def test_effdet_ragged_and_empty_annotations(golden_dir, case):
     assert np.isfinite(gn) and ((gn == 0.0) if case == 'empty' else (gn > 0.0))
 
 
+def test_effdet_atomic_weight_gradient_mode(golden_dir, monkeypatch):
+    """MI355_WGRAD=atomic (fp32 atomics for the conv weight gradients, ungrouped head convs) stays a working mode: same
+    losses, gradients equal to the default slab mode up to the order of fp32 additions."""
+    g, model, img, ann, sd, coef, nc = _build('effdet_d0_128', golden_dir)
+
+    def run(m):
+        m.zero_grad()
+        cl, rl = m(img, ann)
+        (cl.mean() + rl.mean()).backward()
+        return torch.stack([cl.detach().reshape(()), rl.detach().reshape(())]), \
+            torch.cat([q.grad.reshape(-1) for q in m.parameters() if q.grad is not None]).clone()
+    l0, g0 = run(model)
+    monkeypatch.setenv('MI355_WGRAD', 'atomic')
+    _, model2, _, _, _, _, _ = _build('effdet_d0_128', golden_dir)
+    l1, g1 = run(model2)
+    assert torch.equal(l0, l1)
+    assert float((g0 - g1).norm() / g0.norm()) < 1e-4
+
+
 def test_effdet_decode_tail(golden_dir):
     g, model, img, ann, sd, coef, nc = _build('effdet_d2_128x256', golden_dir)
     model.eval()

@@ -105,3 +105,23 @@ def test_kseven_trainer_step(golden_dir):
         l1 = tr.step(img, ann)
     assert torch.isfinite(l1).all() and tr.step_count == 4
     np.testing.assert_allclose(l0.cpu().numpy(), [g['cls_loss'].item(), g['reg_loss'].item()], rtol=4e-2)
+
+
+@pytest.mark.parametrize('tag', ['kseven_r18_fpn_128x160', 'kseven_r18_panet_128'])
+def test_kseven_gradients_are_bit_reproducible(golden_dir, tag):
+    """The tower convs are shared by the five levels (each with its own folded BN): their dW is the sum of five per-level
+    contributions, added in chain order by the parameter-gradient table (Mi355LayerDesc.share_next), not by atomics."""
+    g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
+    dev = torch.device('cuda', 0)
+    model = build(g, dev, 'bf16')
+    (H, W), B, nc = g['hw'], int(g['batch']), int(g['num_classes'])
+    img = torch.from_numpy(synth.synth_images(B, int(H), int(W), seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(B, int(H), int(W), 8, 16, nc, seed=2)).to(dev)
+
+    def run():
+        model.zero_grad()
+        cl, rl = model(img, ann, return_loss=True)
+        (cl.mean() + rl.mean()).backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    a, b = run(), run()
+    assert all(torch.equal(a[k], b[k]) for k in a), [k for k in a if not torch.equal(a[k], b[k])]
