@@ -124,7 +124,7 @@ def conv_flops(plan):
     for L in plan.fwd_launches:
         spec, probs = L
         for (n, p, q) in probs:
-            f = 2.0 * n * p * q * spec.K * spec.C * spec.T
+            f = 2.0 * n * p * q * spec.K * getattr(spec, 'true_ct', spec.C * spec.T)   # (space-to-depth stem: the real 3 x 49 taps)
             fwd += f
             if spec.need_dgrad:
                 dgrad += f

@@ -103,6 +103,15 @@ int mi355_slab_reduce(const float* ws, int nslabs, int64_t slab_stride, int64_t 
 /* fp32 NCHW [N][C][H][W] -> bf16 NHWC [N][H][W][Cpad] (channels >= C zero). */
 int mi355_nchw_to_nhwc_bf16(const float* in, void* out, int N, int C, int H, int W, int Cpad,
                             void* stream);
+/* Space-to-depth form of the ResNet stem (7x7 / stride 2 / pad 3 over 3 channels -> 4x4 / stride 1 / pad (2, 1) over the
+ * 2x2-blocked image; the reference's `self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)`,
+ * retinanet.py:245): the blocked input [N][H/2][W/2][16] (channels (di, dj, c), 12 used), the derived weights
+ * wp [K][12][4][4] = w[k][c][2a + di - 1][2b + dj - 1] (0 outside the 7x7 window) and the scatter of their gradient back:
+ * dw[k][c][r][s] += dwp[k][(di, dj, c)][a][b].  w / dw: element strides (sk, sc, sr, ss). */
+int mi355_nchw_to_nhwc_s2d_bf16(const float* in, void* out, int N, int H, int W, void* stream);
+int mi355_stem_s2d_pack(const float* w, int64_t sk, int64_t sc, int64_t sr, int64_t ss, int K, float* wp, void* stream);
+int mi355_stem_s2d_unpack_grad(const float* dwp, float* dw, int64_t sk, int64_t sc, int64_t sr, int64_t ss, int K,
+                               void* stream);
 /* Weight preparation: fp32 [K][C][R][S] with arbitrary element strides (sk,sc,sr,ss) ->
  *   w_fwd bf16 [K][R*S][Cpad]  = w * scale[k]          (forward operand)
  *   w_dgr bf16 [C][R*S][K]     = w * scale[k]          (dgrad operand), either may be NULL.

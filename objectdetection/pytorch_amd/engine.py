@@ -58,6 +58,8 @@ class LayerSpec(object):
 
     def geometry(self, H, W):
         """-> (pad_top, pad_left, P, Q) for an H x W input."""
+        if getattr(self, 's2d', False):    # space-to-depth stem: 4x4 / stride 1, pad 2 before and 1 after
+            return 2, 2, H, W
         if self.tf_same:
             P, Q = -(-H // self.stride), -(-W // self.stride)
             eh = self.stride * (P - 1) + 1 + (self.R - 1) - H
@@ -139,6 +141,7 @@ class RetinaPlan(object):
             # efficientdet.py:216) needs this too; its Resizer pads to multiples of 32
             raise ValueError('input must be a multiple of %d, got %dx%d' % (self.input_multiple, H, W))
         self._collect_layers()
+        self._maybe_s2d_stem()
         self._alloc_params()
         self._build_prep()
         self._build_forward()
@@ -274,6 +277,34 @@ class RetinaPlan(object):
         for s in (self.reg_out, self.cls_out):
             s.Kpad = -(-s.K // 64) * 64
 
+    def _maybe_s2d_stem(self):
+        """The ResNet stem (7x7 / stride 2 / pad 3 over 3 channels) as a 4x4 / stride-1 conv over the 2x2 space-to-depth
+        image (conv_aux.hip, 'space-to-depth stem'): 256 instead of 392 reduction columns, 32-B gather pieces.  The
+        spec is re-shaped in place; its master weight / gradient are the derived buffers stem_wp / stem_dwp
+        [K][12][4][4], packed before the weight preparation and scattered back into the real dW after the
+        parameter-gradient table.  bf16 plans, even input sizes; MI355_STEM_S2D=0 keeps the direct form."""
+        s = getattr(self, 'stem', None)
+        self.stem_s2d = bool(
+            s is not None and self.prec != 'fp32' and os.environ.get('MI355_STEM_S2D', '1') != '0' and
+            (s.C, s.R, s.S, s.stride, s.pad) == (3, 7, 7, 2, 3) and not s.tf_same and s.conv.bias is None and
+            self.H % 2 == 0 and self.W % 2 == 0)
+        if not self.stem_s2d:
+            return
+        s.true_ct = s.C * s.T                      # FLOP accounting keeps the 3 x 49 taps of the real conv
+        s.s2d = True
+        s.C, s.Cpad, s.R, s.S, s.T, s.stride, s.pad = 12, 16, 4, 4, 16, 1, 2
+        self.stem_wp = self.new((s.K, 12, 4, 4), torch.float32, zero=True)
+        self.stem_dwp = self.new((s.K, 12, 4, 4), torch.float32, zero=True)
+
+    def _stem_unpack_grad(self, arena, stream):
+        """dW of the real 7x7 stem weight += the gradient of its space-to-depth image (after the table launch)."""
+        w = self.stem.conv.weight
+        sk, sc, sr, ss = w.stride()
+        rc = self.lib.mi355_stem_s2d_unpack_grad(ptr(self.stem_dwp), ptr(self.grad_view(w, arena)), c_i64(sk), c_i64(sc),
+                                                 c_i64(sr), c_i64(ss), c_int(self.stem.K), c_vp(stream))
+        if rc:
+            raise _lib.Mi355Error('stem_s2d_unpack_grad: %s' % self.lib.mi355_last_error().decode())
+
     def _alloc_params(self):
         """bf16 shadow arena, folded-BN arena, raw-wgrad scratch arena, and the flat parameter-
         gradient arena (one tensor: a single RCCL all-reduce covers every gradient)."""
@@ -341,8 +372,13 @@ class RetinaPlan(object):
         """Mi355LayerDesc of one conv layer (prep fields; gradient fields when `arena` is given)."""
         d = ops_conv.LayerDesc()
         w = s.conv.weight
-        d.w = w.data_ptr()
-        d.sk, d.sc, d.sr, d.ss = w.stride()
+        s2d = getattr(s, 's2d', False)
+        if s2d:                                # the derived [K][12][4][4] image of the 7x7 stem weight
+            d.w = self.stem_wp.data_ptr()
+            d.sk, d.sc, d.sr, d.ss = self.stem_wp.stride()
+        else:
+            d.w = w.data_ptr()
+            d.sk, d.sc, d.sr, d.ss = w.stride()
         d.K, d.C, d.R, d.S, d.Cpad, d.Kpad = s.K, s.C, s.R, s.S, s.Cpad, s.Kpad
         d.f32_shadows = 1 if self.prec == 'fp32' else 0
         bn = s.folded_bn                      # (train-mode BN is not folded: plain weights, dW = G)
@@ -357,7 +393,7 @@ class RetinaPlan(object):
             d.G, d.colsum = s.G.data_ptr(), s.colsum.data_ptr()
             if self.deterministic:
                 d.nslabs, d.slab_stride = s.nslabs, s.Kpad * s.T * s.Cpad
-            d.dW = self.grad_view(w, arena).data_ptr()
+            d.dW = self.stem_dwp.data_ptr() if s2d else self.grad_view(w, arena).data_ptr()
             if bn is not None:
                 d.dgamma = self.grad_view(bn.weight, arena).data_ptr()
                 d.dbeta = self.grad_view(bn.bias, arena).data_ptr()
@@ -369,6 +405,11 @@ class RetinaPlan(object):
     def _build_prep(self):
         """ONE launch: frozen-BN fold + bf16 forward / dgrad weight shadows of every conv layer."""
         descs, nb = [], 0
+        if getattr(self, 'stem_s2d', False):
+            w = self.stem.conv.weight
+            sk, sc, sr, ss = w.stride()
+            self._step(self.prep_steps, 'mi355_stem_s2d_pack', ptr(w), c_i64(sk), c_i64(sc), c_i64(sr), c_i64(ss),
+                       c_int(self.stem.K), ptr(self.stem_wp))
         for s in self.specs:
             d = self._layer_desc(s)
             d.block_begin = nb
@@ -618,7 +659,7 @@ class RetinaPlan(object):
 
     def _stem_fwd(self):
         B, H, W = self.B, self.H, self.W
-        self.img_nhwc = self.new((B, H, W, 8))
+        self.img_nhwc = self.new((B, H // 2, W // 2, 16)) if self.stem_s2d else self.new((B, H, W, 8))
         x = self.conv(self.stem, self.img_nhwc, ACT_RELU)
         self.c1 = x
         if not self.has_maxpool:                   # RetinaNetTiny: retinanet.py:583-586
@@ -916,6 +957,10 @@ class RetinaPlan(object):
         rc = self.lib.mi355_param_grads_table(ptr(tab[0]), c_int(tab[1]), c_int(tab[2]), c_vp(stream))
         if rc:
             raise _lib.Mi355Error('param_grads_table: %s' % self.lib.mi355_last_error().decode())
+        if getattr(self, 'stem_s2d', False):
+            off = self.grad_offsets[id(self.stem.conv.weight)]
+            if segment is None or segment[0] <= off < segment[1]:
+                self._stem_unpack_grad(arena, stream)          # same stream, behind the table launch
 
     def backward_segments(self, min_bytes=32 << 20):
         """Cut the backward pass for an overlapped data-parallel exchange: [(n_steps, lo, hi)] in execution
@@ -963,9 +1008,13 @@ class RetinaPlan(object):
         if img.dtype != torch.float32:
             img = img.float()
         self._img_ref = img
-        to_nhwc = self.lib.mi355_nchw_to_nhwc_f32 if self.prec == 'fp32' else self.lib.mi355_nchw_to_nhwc_bf16
-        rc = to_nhwc(ptr(img), ptr(self.img_nhwc), c_int(self.B), c_int(3),
-                     c_int(self.H), c_int(self.W), c_int(8), c_vp(st))
+        if getattr(self, 'stem_s2d', False):
+            rc = self.lib.mi355_nchw_to_nhwc_s2d_bf16(ptr(img), ptr(self.img_nhwc), c_int(self.B), c_int(self.H),
+                                                      c_int(self.W), c_vp(st))
+        else:
+            to_nhwc = self.lib.mi355_nchw_to_nhwc_f32 if self.prec == 'fp32' else self.lib.mi355_nchw_to_nhwc_bf16
+            rc = to_nhwc(ptr(img), ptr(self.img_nhwc), c_int(self.B), c_int(3),
+                         c_int(self.H), c_int(self.W), c_int(8), c_vp(st))
         if rc:
             raise _lib.Mi355Error('nchw_to_nhwc: %s' % self.lib.mi355_last_error().decode())
         self._run(self.prep_steps, st)
@@ -994,6 +1043,8 @@ class RetinaPlan(object):
         self.glosses[1:2].copy_(g_reg.reshape(1) if g_reg is not None else torch.zeros(1, device=self.dev))
         self.grad_arenas[arena].zero_()
         self.scratch.zero_()
+        if getattr(self, 'stem_s2d', False):
+            self.stem_dwp.zero_()
         self._zero_extra()
         annot = self._annot
         _lib.call('mi355_focal_loss_bwd', ptr(self.cls), ptr(self.reg), ptr(self._anchors), ptr(annot),

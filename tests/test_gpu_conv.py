@@ -271,6 +271,51 @@ def test_grouped_launch_with_per_problem_weights(dev, ksplit):
     assert not torch.equal(outs[0][:, :4, :5], outs[2])          # (the levels really used different weights)
 
 
+def test_space_to_depth_stem(dev):
+    """The 7x7 / stride-2 / pad-3 stem as a 4x4 / stride-1 conv over the 2x2 space-to-depth image (conv_aux.hip): the packed
+    weights reproduce F.conv2d, and the gradient of the packed weights scatters back onto the 7x7 weight (every element
+    exactly once, the taps outside the 7x7 window dropped)."""
+    from objectdetection.pytorch_amd import ops_conv
+    from objectdetection.pytorch_amd._lib import call, ptr, c_int, c_i64, stream_of
+    N, H, W, K = 2, 32, 40, 64
+    x = _mk((N, 3, H, W), 1)
+    w = _mk((K, 3, 7, 7), 2, scale=(2.0 / 147) ** 0.5)
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last)
+    sk, sc, sr, ss = wd.stride()
+    wp = torch.full((K, 12, 4, 4), float('nan'), device=dev)
+    call('mi355_stem_s2d_pack', ptr(wd), c_i64(sk), c_i64(sc), c_i64(sr), c_i64(ss), c_int(K), ptr(wp), stream_of(wd))
+    ref_wp = torch.zeros((K, 12, 4, 4))
+    for di in range(2):
+        for dj in range(2):
+            for a in range(4):
+                for b in range(4):
+                    r, s2 = 2 * a + di - 1, 2 * b + dj - 1
+                    if 0 <= r < 7 and 0 <= s2 < 7:
+                        ref_wp[:, (di * 2 + dj) * 3:(di * 2 + dj) * 3 + 3, a, b] = w[:, :, r, s2]
+    assert torch.equal(wp.cpu(), ref_wp)
+    xs = torch.empty((N, H // 2, W // 2, 16), dtype=torch.bfloat16, device=dev)
+    call('mi355_nchw_to_nhwc_s2d_bf16', ptr(x.to(dev)), ptr(xs), c_int(N), c_int(H), c_int(W), stream_of(xs))
+    ref_xs = x.reshape(N, 3, H // 2, 2, W // 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(N, H // 2, W // 2, 12)
+    assert torch.equal(xs[..., :12].float().cpu(), ref_xs.to(torch.bfloat16).float()) and float(xs[..., 12:].abs().max()) == 0.0
+    w_fwd = torch.zeros((K, 16, 16), dtype=torch.bfloat16, device=dev)
+    ops_conv.prep_weight(wp, 16, None, w_fwd, None)
+    out = torch.empty((N, H // 2, W // 2, K), dtype=torch.bfloat16, device=dev)
+    pr = ops_conv.fwd_problem(xs, out.data_ptr(), 4, 4, 1, (2, 2), K=K, out_size=(H // 2, W // 2))
+    ops_conv.launch_gather([pr], w_fwd, K, 16, xs)
+    _close(out.permute(0, 3, 1, 2), F.conv2d(x, w, None, 2, 3), 2e-2)
+    # gradient scatter (+=), on top of an existing gradient
+    dwp = _mk((K, 12, 4, 4), 3).float().to(dev)
+    base = _mk((K, 3, 7, 7), 4).float()
+    dw = base.to(dev).contiguous(memory_format=torch.channels_last)
+    call('mi355_stem_s2d_unpack_grad', ptr(dwp), ptr(dw), c_i64(sk), c_i64(sc), c_i64(sr), c_i64(ss), c_int(K), stream_of(dw))
+    ref_dw = base.clone()
+    for r in range(7):
+        for s2 in range(7):
+            a, di, b, dj = (r + 1) >> 1, (r + 1) & 1, (s2 + 1) >> 1, (s2 + 1) & 1
+            ref_dw[:, :, r, s2] += dwp.cpu()[:, (di * 2 + dj) * 3:(di * 2 + dj) * 3 + 3, a, b]
+    assert torch.equal(dw.cpu(), ref_dw)
+
+
 def test_param_grads_with_frozen_bn(dev):
     """dW, dgamma, dbeta of conv -> BN(eval) from the raw wgrad + column sums."""
     from objectdetection.pytorch_amd import ops_conv
