@@ -585,15 +585,16 @@ __global__ __launch_bounds__(256, 2) void conv_gather_ring_kernel(const LaunchDe
 // "virtual output pixel" m0 - 1 + j; output row i and column tap s read staged row i + s.
 // STAGES = 1: one activation buffer + one weight buffer (33 KiB): three blocks per CU, the DMA latency is
 // hidden by the resident waves instead of a second stage (as in the generic one-stage kernel).
-template <int WM, int STAGES = 2>
-__global__ __launch_bounds__(WM * 128, STAGES == 1 ? 3 : 2) void conv_gather_row3_kernel(const LaunchDev L) {
-    constexpr int NTHREADS = WM * 128, BM = WM * 64;
+template <int WM, int STAGES = 2, int TA = 4>
+__global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : (STAGES == 1 ? 3 : 2)) void conv_gather_row3_kernel(const LaunchDev L) {
+    static_assert(TA == 4 || WM == 2, "narrow tile: 4 waves");
+    constexpr int NTHREADS = WM * 128, BM = WM * 64, BNT = TA == 4 ? 128 : 64;
     constexpr int AROWS = BM + 8;                      // staged rows (BM + 2 used), 8-row DMA granules
     constexpr int A_BYTES = AROWS * BK * 2;
     constexpr int Z_ROW = (AROWS - 1) * 128;           // staged rows >= BM + 2 are never in range: zeros
     constexpr int B_OFF = STAGES * A_BYTES;
-    constexpr int B_BYTES = BN * BK * 2;
-    constexpr int NB = 1024 / NTHREADS;
+    constexpr int B_BYTES = BNT * BK * 2;
+    constexpr int NB = BNT * 8 / NTHREADS;
     constexpr int ROWSTEP = NTHREADS / 8;
     constexpr int NA = (AROWS + ROWSTEP - 1) / ROWSTEP;   // A DMA passes (the last one partial)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(WM * 128, STAGES == 1 ? 3 : 2) void conv_gather_row
         if (i < L.nprob && m_tile >= L.p[i].tile_begin) pi = i;
     const ProbDev P = L.p[pi];
     const int m0 = (m_tile - P.tile_begin) * BM;
-    const int n0 = n_tile * BN;
+    const int n0 = n_tile * BNT;
     const int PQ = P.P * P.Q;
 
     if (tid < BM) {
@@ -692,15 +693,15 @@ __global__ __launch_bounds__(WM * 128, STAGES == 1 ? 3 : 2) void conv_gather_row
         }
     };
 
-    const int wm = wv >> 1, wn = wv & 1;
+    const int wrow0 = TA == 4 ? (wv >> 1) * 64 : wv * 32, wn = TA == 4 ? (wv & 1) : 0;
     const int fr = lane & 15, fq = lane >> 4;
-    f4v acc[4][4];
+    f4v acc[TA][4];
     // fragment addresses: output row i = wm*64 + t*16 + fr reads staged row i + s (s = 0, 1, 2);
     // lanes whose column q + s - 1 leaves [0, Q) read the zero row instead.
-    int a_rd[4][3];
+    int a_rd[TA][3];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int i = wm * 64 + t * 16 + fr;
+    for (int t = 0; t < TA; ++t) {
+        const int i = wrow0 + t * 16 + fr;
         const int m = min(m0 + i, P.M - 1);
         const int n = (int)fdiv((unsigned)m, P.dPQ), rem = m - n * PQ;
         const int p = (int)fdiv((unsigned)rem, P.dQ), q = rem - p * P.Q;
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(WM * 128, STAGES == 1 ? 3 : 2) void conv_gather_row
         issue_a(0);
         issue_b(0);
     }
-    init_acc(acc, L, P.bias, n0, wn, fq);
+    init_acc<TA>(acc, L, P.bias, n0, wn, fq);
 
     int abuf = 0, step = 0;
     for (int group = 0; group < ngroups; ++group) {
@@ -740,14 +741,15 @@ __global__ __launch_bounds__(WM * 128, STAGES == 1 ? 3 : 2) void conv_gather_row
             const unsigned char* sb = smem + B_OFF + (STAGES == 2 ? (step & 1) * B_BYTES : 0);
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
-                s8v af[4], bf[4];
+                s8v af[TA], bf[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < TA; ++t)
                     af[t] = *reinterpret_cast<const s8v*>(sa + a_rd[t][sft] + a_sw[sft][sub]);
-                    bf[t] = *reinterpret_cast<const s8v*>(sb + b_rd + t * 16 * 128 + (sub ? b_sw1 : b_sw0));
-                }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int t = 0; t < 4; ++t)
+                    bf[t] = *reinterpret_cast<const s8v*>(sb + b_rd + t * 16 * 128 + (sub ? b_sw1 : b_sw0));
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(WM * 128, STAGES == 1 ? 3 : 2) void conv_gather_row
         abuf ^= 1;
     }
     __syncthreads();
-    gather_epilogue<WM>(acc, L, P, smem, s_outoff, s_addoff, n0);
+    gather_epilogue<WM, TA>(acc, L, P, smem, s_outoff, s_addoff, n0);
 }
 
 // Split-K finish: out = mask( act( sum_s ws[s] + bias (+ addend) ) ) with the generic epilogue's ordering;
@@ -885,7 +887,12 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         const char* e = getenv("MI355_ROW3");
         return e ? atoi(e) : 1;
     }();
-    bool row3 = !flat && row3_mode > 0 && !splitk && !narrow;
+    // ... and its 128x64 form for the narrow launches (MI355_ROW3N=0: the three-stage ring / generic kernel instead)
+    static const int row3n_mode = [] {
+        const char* e = getenv("MI355_ROW3N");
+        return e ? atoi(e) : 1;
+    }();
+    bool row3 = !flat && row3_mode > 0 && !splitk && (!narrow || row3n_mode > 0);
     for (int i = 0; i < in.nprob && row3; ++i) {
         const Mi355ConvProblem& s = in.prob[i];
         // (data gradients walk the taps downwards: dw0 = +1, dws = -1; canonicalised below)
@@ -977,6 +984,12 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     hipStream_t st = (hipStream_t)stream;
     // three-stage ring for the narrow-tile launches that are too small for residency to hide the DMA latency
     static const int ring_mode = [] { const char* e = getenv("MI355_RING"); return e ? atoi(e) : 1; }();
+    if (narrow && row3) {
+        constexpr int ROW3N_B = 64 * BK * 2;
+        if (many) hipLaunchKernelGGL((conv_gather_row3_kernel<2, 1, 2>), g, b256, ROW3_A + ROW3N_B, st, L);
+        else      hipLaunchKernelGGL((conv_gather_row3_kernel<2, 2, 2>), g, b256, 2 * ROW3_A + 2 * ROW3N_B, st, L);
+        return check_launch("conv_gather_row3_kernel<narrow>");
+    }
     if (narrow && !single && !flat && ring_mode && max_ksteps >= 4) {
         static bool ring_attr = false;
         if (!ring_attr) {

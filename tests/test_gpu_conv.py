@@ -55,6 +55,7 @@ CASES = [  # N, H, W, C, K, R, stride, pad
     (3, 5, 7, 256, 36, 3, 1, 1),        # reg output conv (K % 8 != 0)
     (1, 4, 4, 2048, 256, 3, 2, 1),      # P6
     (4, 128, 128, 128, 256, 3, 1, 1),   # >= 1024 tiles of 128x128, long reduction: the wide one-stage kernel
+    (6, 128, 128, 64, 64, 3, 1, 1),     # >= 768 tiles of 128x64: the one-stage form of the narrow row-of-taps kernel
 ]
 
 
