@@ -192,6 +192,8 @@ int mi355_nchw_to_nhwc_f32(const float* in, float* out, int N, int C, int H, int
 int mi355_maxpool3x3s2_fwd_f32(const float* in, float* out, int8_t* idx, int N, int H, int W, int C, void* stream);
 int mi355_maxpool3x3s2_bwd_f32(const float* gout, const int8_t* idx, float* gin, const float* relu_mask,
                                int N, int H, int W, int C, void* stream);
+int mi355_maxpool3x3s2_bwd_pooled_f32(const float* gout, const int8_t* idx, float* gin, const float* pooled,
+                                      int N, int H, int W, int C, void* stream);
 int mi355_sumpool2x2_f32(const float* src, float* dst, int N, int H, int W, int C, int accumulate, void* stream);
 int mi355_relu_mask_f32(const float* x, const float* ref, float* y, int64_t n, void* stream);
 
@@ -200,6 +202,11 @@ int mi355_maxpool3x3s2_fwd(const void* in, void* out, int8_t* idx, int N, int H,
                            void* stream);
 int mi355_maxpool3x3s2_bwd(const void* gout, const int8_t* idx, void* gin, const void* relu_mask,
                            int N, int H, int W, int C, void* stream);
+/* The same behind a ReLU (retinanet.py:275-276: relu, then maxpool), with the mask taken from the POOLED map
+ * [N][P][Q][C] instead of the pool's input: the argmax cell of a window is positive exactly when the pooled value
+ * is (a window of zeros hands its gradient to a cell whose ReLU gradient is zero).  A quarter of the mask bytes. */
+int mi355_maxpool3x3s2_bwd_pooled(const void* gout, const int8_t* idx, void* gin, const void* pooled,
+                                  int N, int H, int W, int C, void* stream);
 /* Nearest-2x upsample backward: dst[n][p][q][c] (+)= sum of the 2x2 children of src
  * (src [N][H][W][C], dst [N][ceil(H/2)][ceil(W/2)][C], bf16). */
 int mi355_sumpool2x2_bf16(const void* src, void* dst, int N, int H, int W, int C, int accumulate,

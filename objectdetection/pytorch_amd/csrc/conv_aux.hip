@@ -268,16 +268,19 @@ extern "C" int mi355_conv_param_grads(const float* G, const float* w, int64_t sk
 
 // ----------------------------------------------------------------------- max-pool 3x3 s2 p1
 __global__ void maxpool_fwd_kernel(const unsigned short* __restrict__ in, unsigned short* __restrict__ out,
-                                   signed char* __restrict__ idx, int N, int H, int W, int C, int P, int Q) {
+                                   signed char* __restrict__ idx, int N, int H, int W, int C, int P, int Q,
+                                   const FastDiv dc8, const FastDiv dQ, const FastDiv dP) {
+    // (32-bit index arithmetic with launch-constant divisors: the 64-bit div / mod chain cost more than the loads)
     const int c8n = C >> 3;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)N * P * Q * c8n;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned total = (unsigned)N * P * Q * c8n;
     if (t >= total) return;
-    const int c8 = (int)(t % c8n);
-    long long r = t / c8n;
-    const int q = (int)(r % Q);  r /= Q;
-    const int p = (int)(r % P);
-    const int n = (int)(r / P);
+    unsigned r = fdiv(t, dc8);
+    const int c8 = (int)(t - r * c8n);
+    const unsigned r2 = fdiv(r, dQ);
+    const int q = (int)(r - r2 * Q);
+    const int n = (int)fdiv(r2, dP);
+    const int p = (int)(r2 - n * P);
     float best[8];
     int bi[8];
 #pragma unroll
@@ -305,8 +308,8 @@ __global__ void maxpool_fwd_kernel(const unsigned short* __restrict__ in, unsign
         o[e] = (short)f32_to_bf16_rn(best[e]);
         packed |= (unsigned long long)(bi[e] & 0xff) << (8 * e);
     }
-    *reinterpret_cast<s8v*>(out + t * 8) = o;
-    *reinterpret_cast<unsigned long long*>(idx + t * 8) = packed;
+    *reinterpret_cast<s8v*>(out + (long long)t * 8) = o;
+    *reinterpret_cast<unsigned long long*>(idx + (long long)t * 8) = packed;
 }
 
 extern "C" int mi355_maxpool3x3s2_fwd(const void* in, void* out, int8_t* idx, int N, int H, int W, int C,
@@ -314,8 +317,10 @@ extern "C" int mi355_maxpool3x3s2_fwd(const void* in, void* out, int8_t* idx, in
     MI355_REQUIRE(in && out && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_fwd: bad args");
     const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * P * Q * (C / 8);
+    MI355_REQUIRE(total < 0x7fffffffLL, "maxpool_fwd: too many cells");
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)in, (unsigned short*)out, (signed char*)idx, N, H, W, C, P, Q);
+                       (const unsigned short*)in, (unsigned short*)out, (signed char*)idx, N, H, W, C, P, Q,
+                       make_fastdiv((unsigned)(C / 8)), make_fastdiv((unsigned)Q), make_fastdiv((unsigned)P));
     return check_launch("maxpool_fwd_kernel");
 }
 
@@ -323,30 +328,53 @@ extern "C" int mi355_maxpool3x3s2_fwd(const void* in, void* out, int8_t* idx, in
 // (p'+a, q'+b), a, b in {0, 1}, whose (argmax, gradient) cells are loaded ONCE for the four pixels (a thread per
 // input pixel loaded 2.25 cells per pixel on average).  Window (p, q) covers rows 2p-1 .. 2p+1: pixel row
 // 2p'+dh sits at window row dh + 1 - 2a, likewise for columns; contributions are added in (p, q) order.
+// relu_mask: the pool's input (ReLU output, input resolution) - or, POOLED, the pool's OUTPUT: behind a ReLU the
+// argmax cell is positive exactly when the pooled value is (a window of zeros sends its gradient to a cell whose
+// ReLU gradient is zero), so the quarter-size pooled map carries the whole mask.
+template <bool POOLED>
 __global__ void maxpool_bwd_kernel(const unsigned short* __restrict__ gout, const signed char* __restrict__ idx,
                                    unsigned short* __restrict__ gin, const unsigned short* __restrict__ relu_mask,
-                                   int N, int H, int W, int C, int P, int Q) {
+                                   int N, int H, int W, int C, int P, int Q,
+                                   const FastDiv dc8, const FastDiv dW2, const FastDiv dH2) {
     const int c8n = C >> 3;
     const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)N * H2 * W2 * c8n) return;
-    const int c8 = (int)(t % c8n);
-    long long r = t / c8n;
-    const int q2 = (int)(r % W2);  r /= W2;
-    const int p2 = (int)(r % H2);
-    const int n = (int)(r / H2);
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (unsigned)N * H2 * W2 * c8n) return;
+    const unsigned r = fdiv(t, dc8);
+    const int c8 = (int)(t - r * c8n);
+    const unsigned r2 = fdiv(r, dW2);
+    const int q2 = (int)(r - r2 * W2);
+    const int n = (int)fdiv(r2, dH2);
+    const int p2 = (int)(r2 - n * H2);
     float acc[2][2][8];
 #pragma unroll
     for (int i = 0; i < 32; ++i) (&acc[0][0][0])[i] = 0.0f;
+    // the four cells' loads first, unconditionally (clamped addresses, an out-of-range cell gets slot 0xff): one
+    // memory round trip per thread instead of one per cell behind its range test
+    unsigned long long pk4[2][2];
+    s8v g4[2][2], m4[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int p = p2 + a, q = q2 + b;
-            if (p >= P || q >= Q) continue;
+            const int p = min(p2 + a, P - 1), q = min(q2 + b, Q - 1);
             const long long o = (((long long)n * P + p) * Q + q) * C + c8 * 8;
-            const unsigned long long pk = *reinterpret_cast<const unsigned long long*>(idx + o);
-            const s8v g = *reinterpret_cast<const s8v*>(gout + o);
+            pk4[a][b] = *reinterpret_cast<const unsigned long long*>(idx + o);
+            g4[a][b] = *reinterpret_cast<const s8v*>(gout + o);
+            if (POOLED) m4[a][b] = *reinterpret_cast<const s8v*>(relu_mask + o);
+        }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const unsigned long long pk = (p2 + a < P && q2 + b < Q) ? pk4[a][b] : ~0ull;
+            s8v g = g4[a][b];
+            if (POOLED) {
+                const s8v m = m4[a][b];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)                    // bf16 > 0  <=>  sign clear and not +-0
+                    g[e] = ((unsigned short)m[e] & 0x8000u) || !((unsigned short)m[e] & 0x7fffu) ? (short)0 : g[e];
+            }
 #pragma unroll
             for (int dh = 0; dh < 2; ++dh) {
                 const int wr = dh + 1 - 2 * a;                 // window row of input row 2p'+dh
@@ -369,7 +397,7 @@ __global__ void maxpool_bwd_kernel(const unsigned short* __restrict__ gout, cons
             const int h = 2 * p2 + dh, w = 2 * q2 + dw;
             if (h >= H || w >= W) continue;
             const long long o = ((((long long)n * H + h) * W + w) * c8n + c8) * 8;
-            if (relu_mask) {
+            if (!POOLED && relu_mask) {
                 const s8v m = *reinterpret_cast<const s8v*>(relu_mask + o);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (!(bf16_to_f32((unsigned short)m[e]) > 0.0f)) acc[dh][dw][e] = 0.0f;
@@ -386,10 +414,26 @@ extern "C" int mi355_maxpool3x3s2_bwd(const void* gout, const int8_t* idx, void*
     MI355_REQUIRE(gout && idx && gin && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "maxpool_bwd: bad args");
     const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    MI355_REQUIRE(total < 0x7fffffffLL, "maxpool_bwd: too many cells");
+    hipLaunchKernelGGL(maxpool_bwd_kernel<false>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)gout, (const signed char*)idx, (unsigned short*)gin,
-                       (const unsigned short*)relu_mask, N, H, W, C, P, Q);
+                       (const unsigned short*)relu_mask, N, H, W, C, P, Q, make_fastdiv((unsigned)(C / 8)),
+                       make_fastdiv((unsigned)((W + 1) / 2)), make_fastdiv((unsigned)((H + 1) / 2)));
     return check_launch("maxpool_bwd_kernel");
+}
+
+extern "C" int mi355_maxpool3x3s2_bwd_pooled(const void* gout, const int8_t* idx, void* gin, const void* pooled,
+                                             int N, int H, int W, int C, void* stream) {
+    MI355_REQUIRE(gout && idx && gin && pooled && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0,
+                  "maxpool_bwd_pooled: bad args");
+    const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+    MI355_REQUIRE(total < 0x7fffffffLL, "maxpool_bwd: too many cells");
+    hipLaunchKernelGGL(maxpool_bwd_kernel<true>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)gout, (const signed char*)idx, (unsigned short*)gin,
+                       (const unsigned short*)pooled, N, H, W, C, P, Q, make_fastdiv((unsigned)(C / 8)),
+                       make_fastdiv((unsigned)((W + 1) / 2)), make_fastdiv((unsigned)((H + 1) / 2)));
+    return check_launch("maxpool_bwd_kernel<pooled>");
 }
 
 // ----------------------------------------------------------------------- nearest-2x upsample backward
@@ -399,11 +443,8 @@ __global__ void sumpool2x2_kernel(const unsigned short* __restrict__ src, unsign
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)N * P * Q * c8n;
     if (t >= total) return;
-    const int c8 = (int)(t % c8n);
-    long long r = t / c8n;
-    const int q = (int)(r % Q);  r /= Q;
-    const int p = (int)(r % P);
-    const int n = (int)(r / P);
+    int c8, q, p, n;
+    split_cell(t, c8n, Q, P, c8, q, p, n);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (accumulate) {
         const s8v d = *reinterpret_cast<const s8v*>(dst + t * 8);

@@ -56,4 +56,26 @@ __device__ __forceinline__ unsigned fdiv(unsigned x, const FastDiv f) {
     return f.d == 1 ? x : (__umulhi(x, f.mul) >> f.shr);
 }
 
+// Flat cell index t -> (c8, x, y, n) for [n][y][x][c8] with extents (c8n, X, Y): 32-bit divisions whenever the index
+// fits (always, for the tensors of a training step) - three 64-bit div / mod pairs per thread cost the elementwise
+// kernels more instructions than their loads and arithmetic together.
+__device__ __forceinline__ void split_cell(long long t, int c8n, int X, int Y, int& c8, int& x, int& y, int& n) {
+    if ((unsigned long long)t >> 32) {
+        c8 = (int)(t % c8n);
+        long long r = t / c8n;
+        x = (int)(r % X);  r /= X;
+        y = (int)(r % Y);
+        n = (int)(r / Y);
+    } else {
+        const unsigned u = (unsigned)t;
+        const unsigned r = u / (unsigned)c8n;
+        c8 = (int)(u - r * (unsigned)c8n);
+        const unsigned r2 = r / (unsigned)X;
+        x = (int)(r - r2 * (unsigned)X);
+        const unsigned r3 = r2 / (unsigned)Y;
+        y = (int)(r2 - r3 * (unsigned)Y);
+        n = (int)r3;
+    }
+}
+
 }  // namespace mi355

@@ -340,6 +340,7 @@ __global__ void maxpool_fwd_f32_kernel(const float* __restrict__ in, float* __re
     idx[t] = (signed char)bi;
 }
 
+template <bool POOLED>                                  // relu_mask at the pool's output resolution (see conv_aux.hip)
 __global__ void maxpool_bwd_f32_kernel(const float* __restrict__ gout, const signed char* __restrict__ idx,
                                        float* __restrict__ gin, const float* __restrict__ relu_mask,
                                        int N, int H, int W, int C, int P, int Q) {
@@ -361,10 +362,10 @@ __global__ void maxpool_bwd_f32_kernel(const float* __restrict__ gout, const sig
             const int wc = w - (2 * q - 1);
             if (wc < 0 || wc > 2) continue;
             const long long o = (((long long)n * P + p) * Q + q) * C + c;
-            if ((int)idx[o] == wr * 3 + wc) acc += gout[o];
+            if ((int)idx[o] == wr * 3 + wc && (!POOLED || relu_mask[o] > 0.0f)) acc += gout[o];
         }
     }
-    if (relu_mask && !(relu_mask[t] > 0.0f)) acc = 0.0f;
+    if (!POOLED && relu_mask && !(relu_mask[t] > 0.0f)) acc = 0.0f;
     gin[t] = acc;
 }
 
@@ -509,8 +510,18 @@ extern "C" int mi355_maxpool3x3s2_bwd_f32(const float* gout, const int8_t* idx, 
     MI355_REQUIRE(gout && idx && gin && N > 0 && H > 0 && W > 0 && C > 0, "maxpool_bwd_f32: bad args");
     const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)N * H * W * C;
-    hipLaunchKernelGGL(maxpool_bwd_f32_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(maxpool_bwd_f32_kernel<false>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        gout, (const signed char*)idx, gin, relu_mask, N, H, W, C, P, Q);
+    return check_launch("maxpool_bwd_f32_kernel");
+}
+
+extern "C" int mi355_maxpool3x3s2_bwd_pooled_f32(const float* gout, const int8_t* idx, float* gin, const float* pooled,
+                                          int N, int H, int W, int C, void* stream) {
+    MI355_REQUIRE(gout && idx && gin && pooled && N > 0 && H > 0 && W > 0 && C > 0, "maxpool_bwd_pooled_f32: bad args");
+    const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)N * H * W * C;
+    hipLaunchKernelGGL(maxpool_bwd_f32_kernel<true>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       gout, (const signed char*)idx, gin, pooled, N, H, W, C, P, Q);
     return check_launch("maxpool_bwd_f32_kernel");
 }
 

@@ -119,11 +119,8 @@ __global__ void dwconv_fwd_kernel(const T* __restrict__ in, const float* __restr
     const int c8n = C >> 3;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N * P * Q * c8n) return;
-    const int c8 = (int)(t % c8n);
-    long long r = t / c8n;
-    const int q = (int)(r % Q);  r /= Q;
-    const int p = (int)(r % P);
-    const int n = (int)(r / P);
+    int c8, q, p, n;
+    split_cell(t, c8n, Q, P, c8, q, p, n);
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[c8 * 8 + e] : 0.0f;
@@ -153,11 +150,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_s1_kernel(const unsigned short
     const int c8n = C >> 3, Q4 = (Q + 3) >> 2;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N * P * Q4 * c8n) return;
-    const int c8 = (int)(t % c8n);
-    long long r = t / c8n;
-    const int q0 = (int)(r % Q4) * 4;  r /= Q4;
-    const int p = (int)(r % P);
-    const int n = (int)(r / P);
+    int c8, q0, p, n;
+    split_cell(t, c8n, Q4, P, c8, q0, p, n);
+    q0 *= 4;
     float acc[4][8];
 #pragma unroll
     for (int o = 0; o < 4; ++o)
@@ -594,11 +589,8 @@ __global__ void dwconv_dgrad_kernel(const T* __restrict__ dy, const float* __res
     const int c8n = C >> 3;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N * H * W * c8n) return;
-    const int c8 = (int)(t % c8n);
-    long long r = t / c8n;
-    const int w = (int)(r % W);  r /= W;
-    const int h = (int)(r % H);
-    const int n = (int)(r / H);
+    int c8, w, h, n;
+    split_cell(t, c8n, W, H, c8, w, h, n);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int a = 0; a < k; ++a) {
         const int hp = h + pad_t - a;
@@ -644,11 +636,8 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(
     const int c8n = C >> 3, H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N * H2 * W2 * c8n) return;
-    const int c8 = (int)(t % c8n);
-    long long r = t / c8n;
-    const int w2 = (int)(r % W2);  r /= W2;
-    const int h2 = (int)(r % H2);
-    const int n = (int)(r / H2);
+    int c8, w2, h2, n;
+    split_cell(t, c8n, W2, H2, c8, w2, h2, n);
     float acc[2][2][8];
 #pragma unroll
     for (int i = 0; i < 32; ++i) (&acc[0][0][0])[i] = 0.0f;
@@ -1922,11 +1911,8 @@ __global__ __launch_bounds__(256) void bifpn_node_kernel(const T* __restrict__ g
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     float d0 = 0.f, d1 = 0.f, d2 = 0.f;
     if (t < total) {
-        const int c8 = (int)(t % c8n);
-        long long r = t / c8n;
-        const int x = (int)(r % W);  r /= W;
-        const int y = (int)(r % H);
-        const int n = (int)(r / H);
+        int c8, x, y, n;
+        split_cell(t, c8n, W, H, c8, x, y, n);
         float a[8], b[8], c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         load8(in0 + t * 8, a);
         const long long o1 = up1 ? ((((long long)n * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * C + c8 * 8) : t * 8;
@@ -1995,11 +1981,8 @@ __global__ __launch_bounds__(256) void bifpn_node_bwd_kernel(const T* __restrict
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     float d0 = 0.f, d1 = 0.f, d2 = 0.f;
     if (t < total) {
-        const int c8 = (int)(t % c8n);
-        long long r = t / c8n;
-        const int xq = (int)(r % Wq);  r /= Wq;
-        const int yq = (int)(r % Hq);
-        const int n = (int)(r / Hq);
+        int c8, xq, yq, n;
+        split_cell(t, c8n, Wq, Hq, c8, xq, yq, n);
         const float w0 = w[0], w1 = w[1], w2 = w[2];
         float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int dy = 0; dy < step; ++dy)
@@ -2198,11 +2181,8 @@ __global__ void upsample_bwd_axpy_kernel(const T* __restrict__ src, const float*
     const int c8n = C >> 3, P = H >> 1, Q = W >> 1;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N * P * Q * c8n) return;
-    const int c8 = (int)(t % c8n);
-    long long r = t / c8n;
-    const int q = (int)(r % Q);  r /= Q;
-    const int p = (int)(r % P);
-    const int n = (int)(r / P);
+    int c8, q, p, n;
+    split_cell(t, c8n, Q, P, c8, q, p, n);
     const float a = w ? w[wi] : 1.0f;
     float o[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (accumulate) load8(dst + t * 8, o);
@@ -2244,11 +2224,8 @@ __global__ void maxpool_same_fwd_kernel(const T* __restrict__ in, T* __restrict_
     const int c8n = C >> 3;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N * P * Q * c8n) return;
-    const int c8 = (int)(t % c8n);
-    long long r = t / c8n;
-    const int q = (int)(r % Q);  r /= Q;
-    const int p = (int)(r % P);
-    const int n = (int)(r / P);
+    int c8, q, p, n;
+    split_cell(t, c8n, Q, P, c8, q, p, n);
     float best[8];
     int bi[8];
     bool first = true;
@@ -2291,11 +2268,8 @@ __global__ void maxpool_same_bwd_kernel(const T* __restrict__ gout, const signed
     const int c8n = C >> 3;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N * H * W * c8n) return;
-    const int c8 = (int)(t % c8n);
-    long long r = t / c8n;
-    const int w = (int)(r % W);  r /= W;
-    const int h = (int)(r % H);
-    const int n = (int)(r / H);
+    int c8, w, h, n;
+    split_cell(t, c8n, W, H, c8, w, h, n);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (accumulate) load8(gin + t * 8, acc);
     for (int a = 0; a < 3; ++a) {

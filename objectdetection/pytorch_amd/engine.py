@@ -82,6 +82,7 @@ def precision_of(model):
 # entry points that have an fp32-mode twin taking the same arguments (include/mi355det_conv.h)
 F32_TWINS = {'mi355_conv_gather': 'mi355_conv_gather_f32', 'mi355_conv_wgrad_slabs': 'mi355_conv_wgrad_slabs_f32',
              'mi355_maxpool3x3s2_fwd': 'mi355_maxpool3x3s2_fwd_f32', 'mi355_maxpool3x3s2_bwd': 'mi355_maxpool3x3s2_bwd_f32',
+             'mi355_maxpool3x3s2_bwd_pooled': 'mi355_maxpool3x3s2_bwd_pooled_f32',
              'mi355_sumpool2x2_bf16': 'mi355_sumpool2x2_f32', 'mi355_relu_mask_bf16': 'mi355_relu_mask_f32',
              # EfficientDet (include/mi355det_effdet.h)
              'mi355_dwconv_fwd': 'mi355_dwconv_fwd_f32', 'mi355_dwconv_dgrad': 'mi355_dwconv_dgrad_f32',
@@ -854,11 +855,12 @@ class RetinaPlan(object):
         return g
 
     def _stem_bwd(self, g):
-        """max-pool backward (+ ReLU mask of the stem output), stem wgrad only."""
+        """max-pool backward (+ ReLU mask of the stem output, read off the pooled map: a quarter of the bytes), stem
+        wgrad only."""
         if self.has_maxpool:
             g_c1 = self.new(tuple(self.c1.shape))
-            self._step(self.bwd_steps, 'mi355_maxpool3x3s2_bwd', ptr(g), ptr(self.mp_idx), ptr(g_c1),
-                       ptr(self.c1), c_int(self.B), c_int(self.c1.shape[1]), c_int(self.c1.shape[2]), c_int(64))
+            self._step(self.bwd_steps, 'mi355_maxpool3x3s2_bwd_pooled', ptr(g), ptr(self.mp_idx), ptr(g_c1),
+                       ptr(self.mp), c_int(self.B), c_int(self.c1.shape[1]), c_int(self.c1.shape[2]), c_int(64))
             g = g_c1
         self.conv_bwd(self.stem, self.img_nhwc, g, dgrad=False)
 

@@ -273,11 +273,16 @@ def maxpool_fwd(x):
     return out, idx
 
 
-def maxpool_bwd(gout, idx, in_shape, relu_mask=None):
+def maxpool_bwd(gout, idx, in_shape, relu_mask=None, pooled=None):
+    """relu_mask: the pool's input (a ReLU output) - or `pooled`, the pool's output, which carries the same mask."""
     N, H, W, C = in_shape
     gin = torch.empty(in_shape, dtype=torch.bfloat16, device=gout.device)
-    call('mi355_maxpool3x3s2_bwd', ptr(gout), ptr(idx), ptr(gin), ptr(relu_mask), c_int(N), c_int(H),
-         c_int(W), c_int(C), stream_of(gout))
+    if pooled is not None:
+        call('mi355_maxpool3x3s2_bwd_pooled', ptr(gout), ptr(idx), ptr(gin), ptr(pooled), c_int(N), c_int(H),
+             c_int(W), c_int(C), stream_of(gout))
+    else:
+        call('mi355_maxpool3x3s2_bwd', ptr(gout), ptr(idx), ptr(gin), ptr(relu_mask), c_int(N), c_int(H),
+             c_int(W), c_int(C), stream_of(gout))
     return gin
 
 

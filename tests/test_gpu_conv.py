@@ -363,6 +363,16 @@ def test_maxpool_and_friends(dev):
     gin = ops_conv.maxpool_bwd(gy.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16), idx,
                                tuple(xh.shape))
     _close(gin.permute(0, 3, 1, 2), x.grad, 1e-2)
+    # relu -> maxpool (retinanet.py:275-276): the ReLU mask from the pool's input, or from the pooled map (same bits)
+    z = _mk((N, C, H, W), 5).requires_grad_(True)
+    F.max_pool2d(F.relu(z), 3, 2, 1).backward(gy)
+    rh = F.relu(z).detach().permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    out, idx = ops_conv.maxpool_fwd(rh)
+    gyh = gy.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    g_in = ops_conv.maxpool_bwd(gyh, idx, tuple(rh.shape), relu_mask=rh)
+    g_po = ops_conv.maxpool_bwd(gyh, idx, tuple(rh.shape), pooled=out)
+    assert torch.equal(g_in, g_po)
+    _close(g_po.permute(0, 3, 1, 2), z.grad, 1e-2)
     # nearest-upsample backward
     src = _mk((N, C, 9, 7), 3)
     ref = F.avg_pool2d(F.pad(src, (0, 1, 0, 1)), 2) * 4
