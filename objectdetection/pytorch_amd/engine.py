@@ -439,8 +439,11 @@ class RetinaPlan(object):
 
     @staticmethod
     def _pick_ksplit(problems, K, T):
-        """Split the taps x channels reduction over blocks when the output has too few 128x128 tiles
-        to cover the 256 CUs and the reduction is long (P6/P7 convs, the 16x16 stage at batch 16)."""
+        """Split the taps x channels reduction over blocks when the output has too few tiles to cover the 256 CUs and
+        the reduction is long (P6 / P7 convs).  From 64 tiles of 128 x 128 (= 128 of the 128 x 64 tiles the launch
+        then runs with) the unsplit three-stage ring kernel is as fast or faster than split + finish (16 x 16 x 16
+        maps of R50 at batch 16: 2048 -> 512 1x1 23 vs 32 us, 256 -> 256 3x3 20 vs 27 us, 512 -> 512 3x3 42 vs 42 us;
+        MI355_SPLITK_MAX_TILES)."""
         if os.environ.get('MI355_SPLITK', '1') == '0':
             return 1
         C = problems[0].C
@@ -448,7 +451,7 @@ class RetinaPlan(object):
             return 1
         tiles = sum(-(-(p.N * p.P * p.Q) // 128) for p in problems) * (-(-K // 128))
         ksteps = min(p.TR * p.TS for p in problems) * (C // 64)
-        if tiles > 160 or ksteps < 16:
+        if tiles >= int(os.environ.get('MI355_SPLITK_MAX_TILES', '64')) or ksteps < 16:
             return 1
         return max(1, min(ksteps // 8, 384 // tiles))
 
