@@ -366,6 +366,10 @@ constexpr int R3_LDS = (R3_TAB_OFF + R3_TABN * 16 > TK * R3_EPI_LD * 4) ? R3_TAB
 
 __device__ __forceinline__ int r3_gx(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
+// DYN: any image width.  The column of staged pixel i then changes from stage to stage, so the edge pixels (q == 0
+// for the left tap, q == W - 1 for the right one) come from the pixel-row table (.w) instead of fixed fragment
+// addresses: a lane fetches the flags of its four fragment pixels one stage ahead and swaps in the zero row.
+template <bool DYN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -421,6 +425,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
                 const unsigned q = rem - p * (unsigned)P.Q;
                 t.x = (int)n * P.in_sN + ((int)p * P.W + (int)q) * P.C;
                 t.y = (int)p;
+                t.w = (q == 0 ? 1 : 0) | ((int)q == P.W - 1 ? 2 : 0);
                 if (m < m_end && e >= 1) t.z = (int)n * P.dy_sN + (int)rem * L.K;
             }
             tab[e] = t;
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3) {
                 const int row = i + s3;
-                const bool edge = (s3 == 0 && q == 0) || (s3 == 2 && q == P.W - 1);
+                const bool edge = !DYN && ((s3 == 0 && q == 0) || (s3 == 2 && q == P.W - 1));
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int lc = 4 * wc + 2 * t + (p4 >> 1);
@@ -497,17 +502,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
     const bool do_colsum = P.colsum != nullptr && c_tile == 0 && kr == 0 && wc == 0;
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
     const int nsteps = (m_end - m_begin + RM - 1) / RM;
+    // DYN: edge flags of this lane's fragment pixels (sub, h) of a stage, 2 bits each
+    auto edge_flags = [&](int step) {
+        const int tb = (step & 7) * RM + row_lo + 1;
+        return tab[tb].w | (tab[tb + 4].w << 2) | (tab[tb + 32].w << 4) | (tab[tb + 36].w << 6);
+    };
     fill(0);
     __syncthreads();
-    if (nsteps > 0) issue(0, 0);
+    int ef_next = DYN ? edge_flags(0) : 0;          // (table reads before the DMA issue: hipcc drains vmcnt in front
+    if (nsteps > 0) issue(0, 0);                    //  of a plain LDS read that follows a buffer_load ... lds)
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
         const int buf = step & 1;
+        const int ef = ef_next;
         if (((step + 1) & 7) == 0 && step + 1 < nsteps) {
             fill(step + 1);
             __syncthreads();
         }
-        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        if (step + 1 < nsteps) {
+            if (DYN) ef_next = edge_flags(step + 1);       // (read before this step's closing barrier, like issue's rows)
+            issue(step + 1, buf ^ 1);
+        }
         const unsigned sb = lds0 + buf * R3_STAGE;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -522,7 +537,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
             for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const s4v b0 = lds_tr<0>(sb + adx[sub][0][s3][t]), b1 = lds_tr<0>(sb + adx[sub][1][s3][t]);
+                    unsigned x0 = adx[sub][0][s3][t], x1 = adx[sub][1][s3][t];
+                    if (DYN && s3 != 1) {
+                        const int bit = s3 == 0 ? 1 : 2;
+                        x0 = (ef >> (4 * sub)) & bit ? ZROW + half8 : x0;
+                        x1 = (ef >> (4 * sub + 2)) & bit ? ZROW + half8 : x1;
+                    }
+                    const s4v b0 = lds_tr<0>(sb + x0), b1 = lds_tr<0>(sb + x1);
                     bf[s3][t] = (s8v){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
                 }
             lds_wait();
@@ -704,16 +725,28 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
         chunks += mine;
     }
     if (ntaps == 0) return MI355_OK;
-    // row-of-taps kernel: 3x3 / stride 1 / same, C % 64 == 0, image width a power of two <= 64
+    // row-of-taps kernel: 3x3 / stride 1 / same, C % 64 == 0 (widths that do not divide 64: its table-driven edge form)
     static const int row3_on = [] {
         const char* e = getenv("MI355_WG_ROW3");
         return e ? atoi(e) : 1;
     }();
-    bool row3 = row3_on && C % 64 == 0 && ntaps == 9;
+    static const int row3_dyn_on = [] {
+        const char* e = getenv("MI355_WG_ROW3_DYN");
+        return e ? atoi(e) : 1;
+    }();
+    bool row3 = row3_on && C % 64 == 0 && ntaps == 9, row3_dyn = false;   // (dyn: a width that does not divide 64)
     for (int i = 0; i < in.nprob && row3; ++i) {
         const Mi355ConvProblem& q = in.prob[i];
         row3 = q.TR == 3 && q.TS == 3 && q.sh == 1 && q.sw == 1 && q.dhs == 1 && q.dws == 1 && q.dw0 == -1 &&
-               q.Q == q.W && q.W <= 64 && (q.W & (q.W - 1)) == 0;
+               q.Q == q.W;
+        const bool pow2 = (q.W & (q.W - 1)) == 0;
+        if (q.W > 64 || !pow2) {
+            // per-launch A/B at 640 x 640 / 512 x 512 (tools/profile_plan.py): ahead of the generic kernel for K >= 128
+            // and C <= 256 (head towers 193 -> 188 us, layer3 group 224 -> 172 us, layer2 group 218 -> 192 us) and at
+            // width 128 (layer1 group 153 -> 138 us); behind it for K = 64 at width 160 and for C = 512
+            row3_dyn = true;
+            row3 = row3 && row3_dyn_on && (pow2 || (in.K >= 128 && C <= 256));
+        }
     }
     if (in.nprob > 1 && chunks <= MAX_SORTED) {
         int n = 0, rows[MAX_SORTED];
@@ -769,10 +802,12 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
     if (row3) {
         static bool r3_attr = false;
         if (!r3_attr) {
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
             r3_attr = true;
         }
-        hipLaunchKernelGGL(conv_wgrad_row3_kernel, g, dim3(256), R3_LDS, st, L);
+        if (row3_dyn) hipLaunchKernelGGL(conv_wgrad_row3_kernel<true>, g, dim3(256), R3_LDS, st, L);
+        else          hipLaunchKernelGGL(conv_wgrad_row3_kernel<false>, g, dim3(256), R3_LDS, st, L);
     } else if (two) {
         if (flat) hipLaunchKernelGGL((conv_wgrad_kernel<true, 2>), g, dim3(512), lds_bytes(2), st, L);
         else      hipLaunchKernelGGL((conv_wgrad_kernel<false, 2>), g, dim3(512), lds_bytes(2), st, L);

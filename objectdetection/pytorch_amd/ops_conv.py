@@ -151,19 +151,27 @@ def launch_wgrad(problems, K, T, dw, split_rows, stream_tensor, colsum=None, f32
          stream_of(stream_tensor))
 
 
-def wgrad_row3_ok(problems, cpad):
+def wgrad_row3_ok(problems, cpad, kpad=128):
     """Launch takes the row-of-taps wgrad kernel (mirrors the host check in conv_wgrad.hip)."""
     import os
     if os.environ.get('MI355_WG_ROW3', '1') == '0' or cpad % 64:
         return False
+    dyn_on = os.environ.get('MI355_WG_ROW3_DYN', '1') != '0'
+
+    def width_ok(w):
+        pow2 = (w & (w - 1)) == 0
+        if w <= 64 and pow2:
+            return True
+        # widths that do not divide the 64-pixel stage: the table-driven edge form, where it beats the generic kernel
+        return dyn_on and (pow2 or (kpad >= 128 and cpad <= 256))
     return all(p.TR == 3 and p.TS == 3 and p.sh == 1 and p.sw == 1 and p.dhs == 1 and p.dws == 1 and p.dw0 == -1
-               and p.Q == p.W and p.W <= 64 and (p.W & (p.W - 1)) == 0 for p in problems)
+               and p.Q == p.W and width_ok(p.W) for p in problems)
 
 
 def wgrad_tiles(kpad, cpad, taps, problems=None):
     """Output tiles of one pixel chunk of the wgrad launch (mirrors conv_wgrad.hip)."""
     kt = -(-kpad // 128)
-    if problems is not None and taps == 9 and wgrad_row3_ok(problems, cpad):
+    if problems is not None and taps == 9 and wgrad_row3_ok(problems, cpad, kpad):
         return kt * 3 * (cpad // 64)
     return kt * (-(-taps * cpad // 128)) if cpad < 128 else kt * taps * (-(-cpad // 128))
 

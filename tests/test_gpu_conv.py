@@ -192,11 +192,17 @@ def test_conv_wgrad(dev, case):
 
 
 @pytest.mark.parametrize('case', [(3, 5, 16, 64, 64, 3, 1, 1), (1, 3, 64, 128, 136, 3, 1, 1), (2, 32, 32, 64, 256, 3, 1, 1),
-                                  (5, 4, 4, 256, 40, 3, 1, 1), (2, 7, 8, 192, 128, 3, 1, 1)])
+                                  (5, 4, 4, 256, 40, 3, 1, 1), (2, 7, 8, 192, 128, 3, 1, 1),
+                                  # widths that do not divide the 64-pixel stage (640 x 640 inputs: 80 / 40 / 20 / 10 / 5)
+                                  # or exceed it: the table-driven edge form of the kernel
+                                  # (taken for K >= 128 and C <= 256, or a power-of-two width; the others: generic kernel)
+                                  (2, 9, 20, 64, 136, 3, 1, 1), (1, 6, 80, 128, 128, 3, 1, 1), (3, 5, 5, 64, 128, 3, 1, 1),
+                                  (2, 11, 10, 128, 256, 3, 1, 1), (1, 3, 128, 64, 64, 3, 1, 1), (2, 4, 1, 64, 128, 3, 1, 1),
+                                  (1, 13, 40, 256, 192, 3, 1, 1), (1, 2, 160, 64, 64, 3, 1, 1), (2, 9, 20, 64, 72, 3, 1, 1)])
 def test_conv_wgrad_row_of_taps(dev, case):
-    """3x3 / stride 1 / same with a power-of-two width: the kernel that stages dy and the activation rows once
-    per kernel row (conv_wgrad_row3_kernel), images that are not multiples of the 64-pixel stage, several
-    images per stage, chunk splits, and the fp32-atomic as well as the slab output."""
+    """3x3 / stride 1 / same: the kernel that stages dy and the activation rows once per kernel row
+    (conv_wgrad_row3_kernel), images that are not multiples of the 64-pixel stage, several images per stage,
+    chunk splits, and the fp32-atomic as well as the slab output."""
     test_conv_wgrad(dev, case)
     from objectdetection.pytorch_amd import ops_conv
     N, H, W, C, K, R, stride, pad = case
