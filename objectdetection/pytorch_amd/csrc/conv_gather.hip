@@ -828,6 +828,124 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// STREAM: 1x1 / stride-1 convs with a short reduction (C <= 256) whose weights fit in LDS (EfficientNet's expand /
+// project convs on the 256^2 ... 64^2 maps and their data gradients).  The tiled kernels above top out at ~170 tiles
+// per us whatever a tile moves (a 128-pixel tile of a 16 -> 96 conv carries 28 KiB: 2.8 TB/s); here a wave streams
+// 16-pixel rows straight from global memory into the MFMA B operand (a lane's fragment IS 16 contiguous bytes of one
+// pixel: no LDS, no barrier), the weights sit in LDS for the whole block, and the accumulators are the transposed tile
+// with the 16 rows of a fragment pair permuted (row 4g + r of fragment t <-> channel 8g + 4t + r) so that a lane ends
+// up with 8 consecutive output channels of one pixel: one 16-B store, 64 contiguous bytes per pixel and instruction.
+struct PwStream {
+    const unsigned short* x;
+    const unsigned short* w;
+    const float* bias;
+    const unsigned short* addend;
+    const unsigned short* mask;
+    unsigned short* out;
+    long long out_row, add_row;     // elements between consecutive pixels of out / addend
+    int M, C, K, act, mask_first, ntiles;
+};
+
+template <int CS, int PT>
+__global__ __launch_bounds__(256) void conv_pw_stream_kernel(const PwStream S) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CP = CS * 32 + 8;                     // LDS row of a weight row (elements): 16-B aligned, banks staggered
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int KP = (S.K + 31) & ~31;
+    float* s_bias = reinterpret_cast<float*>(smem + (size_t)KP * CP * 2);
+    for (int i = tid; i < KP * (CS * 4); i += 256) {    // [KP][CS * 32] <- w[K][C], zero beyond K / C
+        const int k = i / (CS * 4), c = (i - k * (CS * 4)) * 8;
+        s8v v = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+        if (k < S.K && c < S.C) v = *reinterpret_cast<const s8v*>(S.w + (long long)k * S.C + c);
+        *reinterpret_cast<s8v*>(smem + ((size_t)k * CP + c) * 2) = v;
+    }
+    for (int i = tid; i < KP; i += 256) s_bias[i] = (S.bias && i < S.K) ? S.bias[i] : 0.0f;
+    __syncthreads();
+
+    const int p = lane & 15, g = lane >> 4;
+    // A fragment (weights) of fragment t of a 32-channel group: row i = lane & 15 <-> channel 8 (i >> 2) + 4 t + (i & 3)
+    const int a_row = 8 * (p >> 2) + (p & 3);
+    const unsigned char* a_base = smem + ((size_t)a_row * CP + 8 * g) * 2;
+    const int KG = KP >> 5;
+    for (int st = blockIdx.x * 4 + wv; st < S.ntiles; st += gridDim.x * 4) {
+        const int m0 = st * (PT * 16);
+        s8v xf[PT][CS];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int m = m0 + pt * 16 + p;
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) {
+                const int c = cs * 32 + 8 * g;
+                xf[pt][cs] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < S.M && c < S.C) xf[pt][cs] = *reinterpret_cast<const s8v*>(S.x + (long long)m * S.C + c);
+            }
+        }
+        for (int kg = 0; kg < KG; ++kg) {
+            const int kk = kg * 32 + 8 * g;              // this lane's 8 output channels
+            f4v acc[PT][2];
+            {
+                const f4v b0 = *reinterpret_cast<const f4v*>(s_bias + kk), b1 = *reinterpret_cast<const f4v*>(s_bias + kk + 4);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) { acc[pt][0] = b0; acc[pt][1] = b1; }
+            }
+            const unsigned char* ak = a_base + (size_t)kg * 32 * CP * 2;
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) {
+                const s8v a0 = *reinterpret_cast<const s8v*>(ak + cs * 64);
+                const s8v a1 = *reinterpret_cast<const s8v*>(ak + cs * 64 + 4 * CP * 2);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    acc[pt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, xf[pt][cs], acc[pt][0], 0, 0, 0);
+                    acc[pt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, xf[pt][cs], acc[pt][1], 0, 0, 0);
+                }
+            }
+            if (kk >= S.K) continue;                     // (K % 8 == 0: a lane's 8 channels are in or out together)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int m = m0 + pt * 16 + p;
+                if (m >= S.M) continue;
+                float v[8] = {acc[pt][0][0], acc[pt][0][1], acc[pt][0][2], acc[pt][0][3],
+                              acc[pt][1][0], acc[pt][1][1], acc[pt][1][2], acc[pt][1][3]};
+                s8v mk = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+                if (S.mask) mk = *reinterpret_cast<const s8v*>(S.mask + (long long)m * S.out_row + kk);
+                if (S.mask && S.mask_first) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((unsigned short)mk[e]) > 0.0f ? v[e] : 0.0f;
+                }
+                if (S.addend) {
+                    const s8v ad = *reinterpret_cast<const s8v*>(S.addend + (long long)m * S.add_row + kk);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((unsigned short)ad[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = activate(v[e], S.act);
+                if (S.mask && !S.mask_first) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32((unsigned short)mk[e]) > 0.0f ? v[e] : 0.0f;
+                }
+                s8v o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16_rn(v[e]);
+                *reinterpret_cast<s8v*>(S.out + (long long)m * S.out_row + kk) = o;
+            }
+        }
+    }
+}
+
+template <int CS, int PT>
+static void pw_stream_launch(const PwStream& S, int lds, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_pw_stream_kernel<CS, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr = true;
+    }
+    const int per_cu = lds <= 16384 ? 6 : (lds <= 32768 ? 4 : 2);
+    const int nb = (S.ntiles + 3) / 4;
+    const int grid = nb < 256 * per_cu ? nb : 256 * per_cu;
+    hipLaunchKernelGGL((conv_pw_stream_kernel<CS, PT>), dim3((unsigned)grid), dim3(256), lds, st, S);
+}
+
 }  // namespace
 
 static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void* stream);
@@ -850,6 +968,59 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     int tiles = 0;
     const int C = in.prob[0].C;
     MI355_REQUIRE(C > 0 && C % 8 == 0, "conv_gather: C must be a multiple of 8");
+    // ---- streaming form of the short-reduction 1x1 convs (MI355_PW_STREAM: 0 off, 1 where the tile rate of the tiled
+    //      kernels is the bound, 2 wherever it applies)
+    const char* pw_env = getenv("MI355_PW_STREAM");         // (read per call: the tests switch it)
+    const int pw_mode = pw_env ? atoi(pw_env) : 1;
+    if (pw_mode > 0 && in.nprob == 1 && ksplit == 1 && in.T == 1 && !in.out_f32 && in.K % 8 == 0 && C <= 256) {
+        const Mi355ConvProblem& s = in.prob[0];
+        const long long PQ = (long long)s.P * s.Q, M = (long long)s.N * PQ;
+        const int CS = (C + 31) / 32, KP = (in.K + 31) & ~31;
+        const int lds = KP * (CS * 32 + 8) * 2 + KP * 4;
+        const bool dense =
+            s.TR == 1 && s.TS == 1 && s.sh == 1 && s.sw == 1 && s.dh0 == 0 && s.dw0 == 0 && s.P == s.H && s.Q == s.W &&
+            (s.in_sN == 0 || s.in_sN == (long long)s.H * s.W * C) && s.in && s.out && s.N > 0 && PQ > 0 &&
+            s.out_mh == 1 && s.out_mw == 1 && s.out_oh == 0 && s.out_ow == 0 && s.out_sW >= in.K && s.out_sW % 8 == 0 &&
+            s.out_sH == s.Q * s.out_sW && s.out_sN == PQ * s.out_sW &&
+            (!s.addend || (s.add_shift == 0 && s.add_sW % 8 == 0 && s.add_sH == s.Q * s.add_sW && s.add_sN == PQ * s.add_sW)) &&
+            (((uintptr_t)s.in | (uintptr_t)s.out | (uintptr_t)s.addend | (uintptr_t)s.mask) & 15) == 0 &&
+            M < 0x7fffffffLL && lds <= 65536;
+        // the tiled kernels sustain ~170 tiles per us (128 x 64 each): worth streaming when that, not the bytes, sets
+        // their time
+        const double bytes = 2.0 * (double)M * (C + in.K + (s.addend ? in.K : 0) + (s.mask ? in.K : 0));
+        const double t_tiles = (double)cdiv(M, 128) * (double)cdiv(in.K, 64) / 170.0, t_bytes = bytes / 4.5e6;
+        // ... and when a block streams enough to pay for its copy of the weights (40 -> 240 channels at 64 x 64: 38 KiB of
+        // weights per block against 143 KiB of pixels, 23 us streamed vs ~13 tiled)
+        const int pw_pt = CS <= 2 ? 4 : (CS <= 4 ? 2 : 1);
+        const long long pw_nb = cdiv(cdiv(M, 16 * pw_pt), 4), pw_cap = 256 * (lds <= 16384 ? 6 : (lds <= 32768 ? 4 : 2));
+        const double per_block = 2.0 * (double)M * (C + in.K) / (double)(pw_nb < pw_cap ? pw_nb : pw_cap);
+        if (dense && (pw_mode > 1 || (M >= 32768 && t_tiles > 1.15 * t_bytes && per_block >= 4.0 * lds))) {
+            PwStream S;
+            S.x = (const unsigned short*)s.in;
+            S.w = (const unsigned short*)(s.weight ? s.weight : in.weight);
+            S.bias = s.weight ? s.bias : in.bias;
+            S.addend = (const unsigned short*)s.addend;
+            S.mask = (const unsigned short*)s.mask;
+            S.out = (unsigned short*)s.out;
+            S.out_row = s.out_sW;  S.add_row = s.add_sW;
+            S.M = (int)M;  S.C = C;  S.K = in.K;  S.act = in.act;  S.mask_first = in.flags & 1;
+            MI355_REQUIRE(((uintptr_t)S.w & 15) == 0, "conv_gather: weight alignment");
+            hipStream_t st = (hipStream_t)stream;
+            const int pt = CS <= 2 ? 4 : (CS <= 4 ? 2 : 1);
+            S.ntiles = (int)cdiv(M, 16 * pt);
+            switch (CS) {
+                case 1: pw_stream_launch<1, 4>(S, lds, st); break;
+                case 2: pw_stream_launch<2, 4>(S, lds, st); break;
+                case 3: pw_stream_launch<3, 2>(S, lds, st); break;
+                case 4: pw_stream_launch<4, 2>(S, lds, st); break;
+                case 5: pw_stream_launch<5, 1>(S, lds, st); break;
+                case 6: pw_stream_launch<6, 1>(S, lds, st); break;
+                case 7: pw_stream_launch<7, 1>(S, lds, st); break;
+                default: pw_stream_launch<8, 1>(S, lds, st); break;
+            }
+            return check_launch("conv_pw_stream_kernel");
+        }
+    }
     const bool flat = C % BK != 0;
     int max_ksteps = 0;
     long long grid128 = 0;                             // 128x128 tiles of the launch

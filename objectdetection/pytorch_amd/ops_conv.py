@@ -119,7 +119,7 @@ def dgrad_problems(dy, dx_ptr, H, W, Cin, R, S, stride, pad, addend=None, mask=N
     return probs
 
 
-def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE, out_f32=False, ksplit=1):
+def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE, out_f32=False, ksplit=1, flags=0):
     f32 = weight.dtype == torch.float32            # fp32-accurate mode: every operand fp32 (conv_f32.hip)
     for i in range(0, len(problems), MAX_PROBLEMS):
         chunk = problems[i:i + MAX_PROBLEMS]
@@ -127,7 +127,7 @@ def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE
         for j, pr in enumerate(chunk):
             L.prob[j] = pr
         L.nprob, L.K, L.weight, L.T = len(chunk), K, weight.data_ptr(), T
-        L.act, L.bias, L.out_f32 = act, _dp(bias), 1 if out_f32 else 0
+        L.act, L.bias, L.out_f32, L.flags = act, _dp(bias), 1 if out_f32 else 0, flags
         if f32:
             call('mi355_conv_gather_f32', ctypes.byref(L), stream_of(stream_tensor))
         elif ksplit > 1:      # reduction split over blocks, partial tiles in a scratch workspace

@@ -78,6 +78,49 @@ def test_conv_fwd(dev, case):
     _close(out.permute(0, 3, 1, 2), torch.sigmoid(ref), 2e-3)
 
 
+@pytest.mark.parametrize('case', [(2, 128, 128, 16, 96), (1, 96, 100, 24, 144), (2, 33, 47, 96, 16), (1, 40, 40, 144, 40),
+                                  (1, 31, 29, 240, 40), (3, 17, 19, 40, 240), (1, 64, 64, 200, 24), (1, 30, 30, 256, 72),
+                                  (2, 20, 20, 112, 8), (1, 25, 25, 176, 48)])
+@pytest.mark.parametrize('mode', ['2', '1'])
+def test_pointwise_stream_kernel(dev, case, mode, monkeypatch):
+    """conv_pw_stream_kernel (1x1 / stride 1, C <= 256, weights in LDS: EfficientNet's expand / project convs and their
+    data gradients): every reduction width 1..8 x 32 channels, partial 32-channel output groups, ragged pixel tails,
+    bias, residual addend, the in-place accumulating form of a data gradient, mask before / after the addend, against
+    torch fp32 and BIT-equal... to nothing: the tiled kernel adds in another order, so both are held to the fp32
+    reference.  mode 2 forces the kernel wherever it applies, mode 1 is the product's choice."""
+    from objectdetection.pytorch_amd import ops_conv
+    monkeypatch.setenv('MI355_PW_STREAM', mode)
+    N, H, W, C, K = case
+    x = _mk((N, C, H, W), 21)
+    w = _mk((K, C, 1, 1), 22, scale=(2.0 / C) ** 0.5)
+    b = _mk((K,), 23).float()
+    ref = F.conv2d(x, w, b)
+    _, w_fwd, _ = _shadow(w, dev)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    out = ops_conv.conv_fwd(xh, w_fwd, K, 1, 1, 1, 0, bias=b.to(dev))
+    _close(out.permute(0, 3, 1, 2), ref, 1e-2)
+    out = ops_conv.conv_fwd(xh, w_fwd, K, 1, 1, 1, 0, bias=b.to(dev), act=ops_conv.ACT_RELU)
+    _close(out.permute(0, 3, 1, 2), F.relu(ref), 1e-2)
+    add = _mk((N, K, H, W), 24)
+    addh = add.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    out = ops_conv.conv_fwd(xh, w_fwd, K, 1, 1, 1, 0, bias=b.to(dev), addend=addh)
+    _close(out.permute(0, 3, 1, 2), ref + _bf(add), 1e-2)
+    # in place: out = conv + out (the accumulating data gradient of a tensor with two consumers)
+    acc = addh.clone()
+    pr = ops_conv.fwd_problem(xh, acc.data_ptr(), 1, 1, 1, 0, K=K, addend=acc)
+    ops_conv.launch_gather([pr], w_fwd, K, 1, xh, bias=b.to(dev))
+    _close(acc.permute(0, 3, 1, 2), ref + _bf(add), 1e-2)
+    # ReLU-backward style mask, before and after the addend
+    mk = _mk((N, K, H, W), 25)
+    mkh = mk.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    on = (_bf(mk) > 0).float()
+    for flags, want in ((0, (ref + _bf(add)) * on), (1, ref * on + _bf(add))):
+        o2 = torch.empty_like(addh)
+        pr = ops_conv.fwd_problem(xh, o2.data_ptr(), 1, 1, 1, 0, K=K, addend=addh, mask=mkh)
+        ops_conv.launch_gather([pr], w_fwd, K, 1, xh, bias=b.to(dev), flags=flags)
+        _close(o2.permute(0, 3, 1, 2), want, 1e-2)
+
+
 @pytest.mark.parametrize('case,ksplit', [((1, 4, 4, 2048, 256, 3, 2, 1), 16), ((2, 9, 7, 512, 192, 3, 1, 1), 3),
                                          ((2, 6, 5, 1024, 36, 1, 1, 0), 4)])
 def test_conv_fwd_splitk(dev, case, ksplit):
