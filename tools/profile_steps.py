@@ -62,6 +62,7 @@ for (ph, name, desc), (n, us, nb) in by.items():
 for (ph, name), (n, us, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print('%s %-24s n=%4d %9.1f us  %5.1f %%  %8.1f MB  %6.0f GB/s  floor@5TB/s %7.1f us' %
           (ph, name, n, us, 100 * us / tot, nb / 1e6, nb / us / 1e3 if us else 0, nb / 5e6))
-print('-- by launch shape (top 60)')
-for (ph, name, desc), (n, us, nb) in sorted(by.items(), key=lambda kv: -kv[1][1])[:60]:
+TOPN = int(os.environ.get('TOPN', '60'))
+print('-- by launch shape (top %d)' % TOPN)
+for (ph, name, desc), (n, us, nb) in sorted(by.items(), key=lambda kv: -kv[1][1])[:TOPN]:
     print('%s %-22s %-40s n=%3d %8.1f us/launch %6.0f GB/s  %5.1f %%' % (ph, name, desc, n, us / n, nb / us / 1e3 if us else 0, 100 * us / tot))
