@@ -86,8 +86,8 @@ def test_pointwise_stream_kernel(dev, case, mode, monkeypatch):
     """conv_pw_stream_kernel (1x1 / stride 1, C <= 256, weights in LDS: EfficientNet's expand / project convs and their
     data gradients): every reduction width 1..8 x 32 channels, partial 32-channel output groups, ragged pixel tails,
     bias, residual addend, the in-place accumulating form of a data gradient, mask before / after the addend, against
-    torch fp32 and BIT-equal... to nothing: the tiled kernel adds in another order, so both are held to the fp32
-    reference.  mode 2 forces the kernel wherever it applies, mode 1 is the product's choice."""
+    torch fp32 (the tiled kernels add in another order, so both forms are held to the fp32 reference, not to each
+    other).  mode 2 forces the kernel wherever it applies, mode 1 is the product's choice."""
     from objectdetection.pytorch_amd import ops_conv
     monkeypatch.setenv('MI355_PW_STREAM', mode)
     N, H, W, C, K = case
