@@ -854,11 +854,23 @@ __global__ __launch_bounds__(256) void conv_pw_stream_kernel(const PwStream S) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int KP = (S.K + 31) & ~31;
     float* s_bias = reinterpret_cast<float*>(smem + (size_t)KP * CP * 2);
-    for (int i = tid; i < KP * (CS * 4); i += 256) {    // [KP][CS * 32] <- w[K][C], zero beyond K / C
-        const int k = i / (CS * 4), c = (i - k * (CS * 4)) * 8;
-        s8v v = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
-        if (k < S.K && c < S.C) v = *reinterpret_cast<const s8v*>(S.w + (long long)k * S.C + c);
-        *reinterpret_cast<s8v*>(smem + ((size_t)k * CP + c) * 2) = v;
+    // [KP][CS * 32] <- w[K][C], zero beyond K / C; eight 16-B pieces per thread in flight (one at a time was eight
+    // dependent round trips for a 38 KiB weight block: longer than streaming the block's pixels)
+    for (int i0 = tid; i0 < KP * (CS * 4); i0 += 256 * 8) {
+        s8v v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            const int k = i / (CS * 4), c = (i - k * (CS * 4)) * 8;
+            v[u] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+            if (k < S.K && c < S.C) v[u] = *reinterpret_cast<const s8v*>(S.w + (long long)k * S.C + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            const int k = i / (CS * 4), c = (i - k * (CS * 4)) * 8;
+            if (k < KP) *reinterpret_cast<s8v*>(smem + ((size_t)k * CP + c) * 2) = v[u];
+        }
     }
     for (int i = tid; i < KP; i += 256) s_bias[i] = (S.bias && i < S.K) ? S.bias[i] : 0.0f;
     __syncthreads();
@@ -968,8 +980,8 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     int tiles = 0;
     const int C = in.prob[0].C;
     MI355_REQUIRE(C > 0 && C % 8 == 0, "conv_gather: C must be a multiple of 8");
-    // ---- streaming form of the short-reduction 1x1 convs (MI355_PW_STREAM: 0 off, 1 where the tile rate of the tiled
-    //      kernels is the bound, 2 wherever it applies)
+    // ---- streaming form of the short-reduction 1x1 convs (MI355_PW_STREAM: 0 off, 1 where it was measured ahead of the
+    //      tiled kernels, 2 wherever it applies)
     const char* pw_env = getenv("MI355_PW_STREAM");         // (read per call: the tests switch it)
     const int pw_mode = pw_env ? atoi(pw_env) : 1;
     if (pw_mode > 0 && in.nprob == 1 && ksplit == 1 && in.T == 1 && !in.out_f32 && in.K % 8 == 0 && C <= 256) {
@@ -985,16 +997,15 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
             (!s.addend || (s.add_shift == 0 && s.add_sW % 8 == 0 && s.add_sH == s.Q * s.add_sW && s.add_sN == PQ * s.add_sW)) &&
             (((uintptr_t)s.in | (uintptr_t)s.out | (uintptr_t)s.addend | (uintptr_t)s.mask) & 15) == 0 &&
             M < 0x7fffffffLL && lds <= 65536;
-        // the tiled kernels sustain ~170 tiles per us (128 x 64 each): worth streaming when that, not the bytes, sets
-        // their time
-        const double bytes = 2.0 * (double)M * (C + in.K + (s.addend ? in.K : 0) + (s.mask ? in.K : 0));
-        const double t_tiles = (double)cdiv(M, 128) * (double)cdiv(in.K, 64) / 170.0, t_bytes = bytes / 4.5e6;
-        // ... and when a block streams enough to pay for its copy of the weights (40 -> 240 channels at 64 x 64: 38 KiB of
-        // weights per block against 143 KiB of pixels, 23 us streamed vs ~13 tiled)
-        const int pw_pt = CS <= 2 ? 4 : (CS <= 4 ? 2 : 1);
-        const long long pw_nb = cdiv(cdiv(M, 16 * pw_pt), 4), pw_cap = 256 * (lds <= 16384 ? 6 : (lds <= 32768 ? 4 : 2));
-        const double per_block = 2.0 * (double)M * (C + in.K) / (double)(pw_nb < pw_cap ? pw_nb : pw_cap);
-        if (dense && (pw_mode > 1 || (M >= 32768 && t_tiles > 1.15 * t_bytes && per_block >= 4.0 * lds))) {
+        // Where it wins (per-launch A/B on EfficientDet-D0 and RetinaNet-R50 at batch 16, tools/profile_steps.py /
+        // profile_plan.py with MI355_PW_STREAM=0 / 2): reductions the tiled kernels run in their flat form (C % 64 != 0,
+        // partly empty tiles at ~170 tiles per us whatever a tile carries) on the large maps - 16 -> 96 at 256 x 256
+        // 84 -> 50 us, 96 -> 16 53 -> 38, 32 -> 16 44 -> 21, 144 -> 24 at 128 x 128 24.5 -> 16.4, 144 -> 40 at 64 x 64
+        // 10.1 -> 6.9.  Where it loses: C % 64 == 0 (RetinaNet 64 -> 256 at 128 x 128: 65 tiled vs 93 us), wide outputs
+        // on small maps (a block stages K x C weights for a handful of pixels: 40 -> 240 at 64 x 64 15 vs 22 us,
+        // 64 -> 320 at 16 x 16 6.6 vs 28.6) and everything the tiled kernel finishes in ~6 us.
+        const bool wins = C % 64 != 0 && ((M >= 131072 && in.K <= 144) || (M >= 65536 && C >= 96 && in.K <= 48));
+        if (dense && (pw_mode > 1 || wins)) {
             PwStream S;
             S.x = (const unsigned short*)s.in;
             S.w = (const unsigned short*)(s.weight ? s.weight : in.weight);
