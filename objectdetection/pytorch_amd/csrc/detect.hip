@@ -330,39 +330,40 @@ __global__ __launch_bounds__(FL_TILE) void focal_fwd_kernel(
 }
 
 // Fixed-order reduction of the per-block partials (deterministic), losses.py:118, 161, 168.
-__global__ void focal_finalize_kernel(const float* part_cls, const float* part_reg,
-                                      const int* part_pos, int B, int nblk, float* losses,
-                                      int32_t* num_pos) {
-    __shared__ double s_c[256], s_r[256];
-    __shared__ int s_p[256];
-    __shared__ float s_lc, s_lr;
-    const int tid = threadIdx.x;
-    if (tid == 0) { s_lc = 0.0f; s_lr = 0.0f; }
-    for (int b = 0; b < B; ++b) {
+__global__ __launch_bounds__(1024) void focal_finalize_kernel(const float* part_cls, const float* part_reg,
+                                                              const int* part_pos, int B, int nblk, float* losses,
+                                                              int32_t* num_pos) {
+    // one wave per image (16 at a time; one block of 256 threads walking the images one after another with a barrier
+    // tree each took 22 us at batch 16): lane-strided partial sums in fp64, a fixed shuffle tree, then thread 0 adds the
+    // images in index order
+    extern __shared__ float s_img[];                   // [B][2]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int b = wv; b < B; b += 16) {
         double c = 0, r = 0;
         int p = 0;
-        for (int i = tid; i < nblk; i += 256) {
+        for (int i = lane; i < nblk; i += 64) {
             c += part_cls[(size_t)b * nblk + i];
             r += part_reg[(size_t)b * nblk + i];
             p += part_pos[(size_t)b * nblk + i];
         }
-        s_c[tid] = c; s_r[tid] = r; s_p[tid] = p;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) { s_c[tid] += s_c[tid + o]; s_r[tid] += s_r[tid + o]; s_p[tid] += s_p[tid + o]; }
-            __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            c += __shfl_down(c, o, 64);
+            r += __shfl_down(r, o, 64);
+            p += __shfl_down(p, o, 64);
         }
-        if (tid == 0) {
-            const int np = s_p[0];
-            num_pos[b] = np;
-            s_lc += __fdiv_rn((float)s_c[0], fmaxf((float)np, 1.0f));
-            if (np > 0) s_lr += __fdiv_rn((float)s_r[0], (float)(4 * np));
+        if (lane == 0) {
+            num_pos[b] = p;
+            s_img[2 * b] = __fdiv_rn((float)c, fmaxf((float)p, 1.0f));
+            s_img[2 * b + 1] = p > 0 ? __fdiv_rn((float)r, (float)(4 * p)) : 0.0f;
         }
-        __syncthreads();
     }
-    if (tid == 0) {
-        losses[0] = __fdiv_rn(s_lc, (float)B);
-        losses[1] = __fdiv_rn(s_lr, (float)B);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lc = 0.0f, lr = 0.0f;
+        for (int b = 0; b < B; ++b) { lc += s_img[2 * b]; lr += s_img[2 * b + 1]; }
+        losses[0] = __fdiv_rn(lc, (float)B);
+        losses[1] = __fdiv_rn(lr, (float)B);
     }
 }
 
@@ -404,7 +405,7 @@ extern "C" int mi355_focal_loss_fwd(const float* cls, const float* reg, const fl
                            state, part_cls, part_reg, part_pos);
     int rc = check_launch("focal_fwd_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part_cls,
+    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(1024), (size_t)B * 2 * sizeof(float), (hipStream_t)stream, part_cls,
                        part_reg, part_pos, B, nblk, losses, num_pos);
     return check_launch("focal_finalize_kernel");
 }
