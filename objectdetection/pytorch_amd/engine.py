@@ -1044,16 +1044,22 @@ class RetinaPlan(object):
         st = self._stream()
         arena = self._arena_for_backward()
         self.last_arena = arena
-        self.glosses[0:1].copy_(g_cls.reshape(1) if g_cls is not None else torch.zeros(1, device=self.dev))
-        self.glosses[1:2].copy_(g_reg.reshape(1) if g_reg is not None else torch.zeros(1, device=self.dev))
+        gl = self.glosses
+        if g_cls is not None and g_reg is not None and g_cls.dtype == torch.float32 and g_reg.dtype == torch.float32 and \
+                g_cls.device == self.dev and g_reg.data_ptr() == g_cls.data_ptr() + 4:
+            gl = g_cls                                 # (the trainer's pair of ones: adjacent floats, no staging copies)
+        else:
+            gl[0:1].copy_(g_cls.reshape(1) if g_cls is not None else torch.zeros(1, device=self.dev))
+            gl[1:2].copy_(g_reg.reshape(1) if g_reg is not None else torch.zeros(1, device=self.dev))
         self.grad_arenas[arena].zero_()
-        self.scratch.zero_()
+        if self.scratch.numel() > 1:                   # (atomic mode's raw gradients; the slab mode has none)
+            self.scratch.zero_()
         if getattr(self, 'stem_s2d', False):
             self.stem_dwp.zero_()
         self._zero_extra()
         annot = self._annot
         _lib.call('mi355_focal_loss_bwd', ptr(self.cls), ptr(self.reg), ptr(self._anchors), ptr(annot),
-                  ptr(self.argmax), ptr(self.state), ptr(self.num_pos), ptr(self.glosses),
+                  ptr(self.argmax), ptr(self.state), ptr(self.num_pos), ptr(gl),
                   c_int(self.B), c_int(self.A), c_int(self.num_classes), c_int(annot.shape[1]),
                   c_f32(ops_detect.ALPHA), c_int(2 if self.prec == 'fp32' else 1), ptr(self.gcls), ptr(self.greg),
                   c_int(self.A_cell), c_int(self.cls_pitch), c_int(self.reg_pitch), c_vp(st))
