@@ -78,8 +78,12 @@ __device__ __forceinline__ void lds_wait() {
     __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs behind the wait (guide §5.4 rule 18)
 }
 
-template <bool FLAT, int NG>
+// KH (K <= 64, NG 1): the upper half of the k-tile is empty; the four waves take 64 x 32 column strips of the
+// 64 x 128 tile (NJ = 2 fragment columns) instead of two of them multiplying zeros.
+template <bool FLAT, int NG, bool KH = false>
 __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L) {
+    static_assert(!KH || NG == 1, "K <= 64 form: one wave group");
+    constexpr int NJ = KH ? 2 : 4;
     constexpr int NTHREADS = 256 * NG, RMS = RM * NG;   // rows per stage
     constexpr int STAGE_BYTES = stage_bytes(NG), TAB_OFF = 2 * STAGE_BYTES, TAB_STEPS = TAB_ROWS / RMS;
     constexpr int ROWSTEP = NTHREADS / 16;              // rows covered by one DMA instruction of the block
@@ -192,15 +196,15 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
         }
     };
 
-    f4v acc[4][4];
+    f4v acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
 
     // transposed-read addressing (16-lane group g, lane 4q+p): row 8g + q (+4), columns 4p..4p+3
     const int grp = wv >> 2;                           // pixel-row group of this wave
-    const int wk = (wv >> 1) & 1, wc = wv & 1;
+    const int wk = KH ? 0 : (wv >> 1) & 1, wc = KH ? wv & 3 : wv & 1;
     const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int f = (q4 | ((g & 1) << 2)) << 1;
     const int row_lo = 8 * g + q4;
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         ady[t] = (grp * RM + row_lo) * 256 + ((8 * wk + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
-        adx[t] = (grp * RM + row_lo) * 256 + ((8 * wc + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
+        adx[t] = (grp * RM + row_lo) * 256 + (((KH ? 4 : 8) * wc + 2 * (t & (NJ - 1)) + (p4 >> 1)) ^ f) * 16 + half8;
     }
 
     // column sums of dy (bias / BN-beta gradient): only the blocks owning (tap 0, c-tile 0) and
@@ -233,21 +237,25 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
         if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
         {
             const unsigned sb = lds0 + buf * STAGE_BYTES;
-            s8v af[2][4], bf[2][4];
+            s8v af[2][4], bf[2][NJ];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const s4v a0 = lds_tr<0>(sb + ady[t]), a1 = lds_tr<1024>(sb + ady[t]);
-                const s4v b0 = lds_tr<XOFF>(sb + adx[t]), b1 = lds_tr<XOFF + 1024>(sb + adx[t]);
                 af[0][t] = (s8v){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                bf[0][t] = (s8v){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                if (t < NJ) {
+                    const s4v b0 = lds_tr<XOFF>(sb + adx[t]), b1 = lds_tr<XOFF + 1024>(sb + adx[t]);
+                    bf[0][t & (NJ - 1)] = (s8v){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                }
             }
             lds_wait();
 #pragma unroll
             for (int t = 0; t < 4; ++t) {              // rows 32..63 fly while rows 0..31 are on the matrix cores
                 const s4v a0 = lds_tr<8192>(sb + ady[t]), a1 = lds_tr<8192 + 1024>(sb + ady[t]);
-                const s4v b0 = lds_tr<XOFF + 8192>(sb + adx[t]), b1 = lds_tr<XOFF + 8192 + 1024>(sb + adx[t]);
                 af[1][t] = (s8v){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                bf[1][t] = (s8v){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                if (t < NJ) {
+                    const s4v b0 = lds_tr<XOFF + 8192>(sb + adx[t]), b1 = lds_tr<XOFF + 8192 + 1024>(sb + adx[t]);
+                    bf[1][t & (NJ - 1)] = (s8v){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                }
             }
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[sub][i], bf[sub][j], acc[i][j], 0, 0, 0);
             }
         }
@@ -287,10 +295,10 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    epi[(wk * 64 + i * 16 + fq * 4 + r) * EPI_LD + wc * 64 + j * 16 + fr] = acc[i][j][r];
+                    epi[(wk * 64 + i * 16 + fq * 4 + r) * EPI_LD + wc * (KH ? 32 : 64) + j * 16 + fr] = acc[i][j][r];
     }
     __syncthreads();
     if (NG > 1) {
@@ -298,10 +306,10 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        epi[(wk * 64 + i * 16 + fq * 4 + r) * EPI_LD + wc * 64 + j * 16 + fr] += acc[i][j][r];
+                        epi[(wk * 64 + i * 16 + fq * 4 + r) * EPI_LD + wc * (KH ? 32 : 64) + j * 16 + fr] += acc[i][j][r];
         }
         __syncthreads();
     }
@@ -369,8 +377,12 @@ __device__ __forceinline__ int r3_gx(int row) { return ((row >> 1) & 1) | (((row
 // DYN: any image width.  The column of staged pixel i then changes from stage to stage, so the edge pixels (q == 0
 // for the left tap, q == W - 1 for the right one) come from the pixel-row table (.w) instead of fixed fragment
 // addresses: a lane fetches the flags of its four fragment pixels one stage ahead and swaps in the zero row.
-template <bool DYN>
+// KH (K <= 64: stem-side layers, the regression output conv): the upper 64 rows of the k-tile are empty, so the four
+// waves split the 64 x 64 tile into 64 x 16 column strips (NJ = 1 fragment column each) instead of two of them
+// multiplying zeros.
+template <bool DYN, bool KH>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L) {
+    constexpr int NJ = KH ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int b = blockIdx.x;
@@ -459,15 +471,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
         }
     };
 
-    f4v acc[3][4][2];
+    f4v acc[3][4][NJ];
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[s3][i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) acc[s3][i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
 
-    const int wk = wv >> 1, wc = wv & 1;
+    const int wk = KH ? 0 : wv >> 1, wc = KH ? wv : wv & 1;
     const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int f = (q4 | ((g & 1) << 2)) << 1;
     const int row_lo = 8 * g + q4;
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
     // activation fragment addresses: [sub][h][shift][t]; pixel i = 32 sub + row_lo + 4 h reads staged row i + s;
     // W | 64 and chunks start at multiples of 64, so the image column of pixel i is i mod W
     constexpr unsigned ZROW = R3_DY_BYTES + (R3_XROWS - 1) * 128;       // staged row 71: always zeros
-    unsigned adx[2][2][3][2];
+    unsigned adx[2][2][3][NJ];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -491,8 +503,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
                 const int row = i + s3;
                 const bool edge = !DYN && ((s3 == 0 && q == 0) || (s3 == 2 && q == P.W - 1));
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int lc = 4 * wc + 2 * t + (p4 >> 1);
+                for (int t = 0; t < NJ; ++t) {
+                    const int lc = (KH ? 2 : 4) * wc + 2 * t + (p4 >> 1);
                     adx[sub][h][s3][t] = edge ? ZROW + half8
                                               : R3_DY_BYTES + row * 128 + ((lc ^ (r3_gx(row) << 1)) << 4) + half8;
                 }
@@ -526,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
         const unsigned sb = lds0 + buf * R3_STAGE;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            s8v af[4], bf[3][2];
+            s8v af[4], bf[3][NJ];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const unsigned a = sb + ady[t] + sub * 8192;
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < NJ; ++t) {
                     unsigned x0 = adx[sub][0][s3][t], x1 = adx[sub][1][s3][t];
                     if (DYN && s3 != 1) {
                         const int bit = s3 == 0 ? 1 : 2;
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[s3][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[s3][j], acc[s3][i][j], 0, 0, 0);
         }
         __syncthreads();
@@ -586,10 +598,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    epi[(wk * 64 + i * 16 + fq * 4 + r) * R3_EPI_LD + wc * 32 + j * 16 + fr] = acc[s3][i][j][r];
+                    epi[(wk * 64 + i * 16 + fq * 4 + r) * R3_EPI_LD + wc * (KH ? 16 : 32) + j * 16 + fr] = acc[s3][i][j][r];
         __syncthreads();
         const long long coff = (long long)((P.r0 + kr * P.rs) * P.S + (P.s0 + s3 * P.ss)) * P.C + c0 + lane;
         for (int rr = wv; rr < TK; rr += 4) {
@@ -605,6 +617,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
 }
 
 }  // namespace
+
+// MI355_WG_K64=0: K <= 64 layers through the 128-row k-tile forms (A/B)
+static int wg_k64_on() {
+    static const int on = [] { const char* e = getenv("MI355_WG_K64"); return e ? atoi(e) : 1; }();
+    return on;
+}
 
 template <bool ALIGNED>
 __global__ void slab_reduce_kernel(const float4* __restrict__ ws, int nslabs, long long slab4, long long n4,
@@ -743,7 +761,8 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
         if (q.W > 64 || !pow2) {
             // per-launch A/B at 640 x 640 / 512 x 512 (tools/profile_plan.py): ahead of the generic kernel for K >= 128
             // and C <= 256 (head towers 193 -> 188 us, layer3 group 224 -> 172 us, layer2 group 218 -> 192 us) and at
-            // width 128 (layer1 group 153 -> 138 us); behind it for K = 64 at width 160 and for C = 512
+            // width 128 (layer1 group 153 -> 138 us); behind it for K = 64 at width 160 (also in the K <= 64 forms: 269 vs
+            // 226 us) and for C = 512
             row3_dyn = true;
             row3 = row3 && row3_dyn_on && (pow2 || (in.K >= 128 && C <= 256));
         }
@@ -793,6 +812,8 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2));
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2));
         attr_set = true;
@@ -802,15 +823,26 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
     if (row3) {
         static bool r3_attr = false;
         if (!r3_attr) {
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);
             r3_attr = true;
         }
-        if (row3_dyn) hipLaunchKernelGGL(conv_wgrad_row3_kernel<true>, g, dim3(256), R3_LDS, st, L);
-        else          hipLaunchKernelGGL(conv_wgrad_row3_kernel<false>, g, dim3(256), R3_LDS, st, L);
+        const bool kh = wg_k64_on() && in.K <= 64;
+        if (row3_dyn) {
+            if (kh) hipLaunchKernelGGL((conv_wgrad_row3_kernel<true, true>), g, dim3(256), R3_LDS, st, L);
+            else    hipLaunchKernelGGL((conv_wgrad_row3_kernel<true, false>), g, dim3(256), R3_LDS, st, L);
+        } else {
+            if (kh) hipLaunchKernelGGL((conv_wgrad_row3_kernel<false, true>), g, dim3(256), R3_LDS, st, L);
+            else    hipLaunchKernelGGL((conv_wgrad_row3_kernel<false, false>), g, dim3(256), R3_LDS, st, L);
+        }
     } else if (two) {
         if (flat) hipLaunchKernelGGL((conv_wgrad_kernel<true, 2>), g, dim3(512), lds_bytes(2), st, L);
         else      hipLaunchKernelGGL((conv_wgrad_kernel<false, 2>), g, dim3(512), lds_bytes(2), st, L);
+    } else if (wg_k64_on() && in.K <= 64) {
+        if (flat) hipLaunchKernelGGL((conv_wgrad_kernel<true, 1, true>), g, dim3(256), lds_bytes(1), st, L);
+        else      hipLaunchKernelGGL((conv_wgrad_kernel<false, 1, true>), g, dim3(256), lds_bytes(1), st, L);
     } else {
         if (flat) hipLaunchKernelGGL((conv_wgrad_kernel<true, 1>), g, dim3(256), lds_bytes(1), st, L);
         else      hipLaunchKernelGGL((conv_wgrad_kernel<false, 1>), g, dim3(256), lds_bytes(1), st, L);
