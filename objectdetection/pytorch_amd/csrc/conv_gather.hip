@@ -845,9 +845,14 @@ struct PwStream {
     unsigned short* out;
     long long out_row, add_row;     // elements between consecutive pixels of out / addend
     int M, C, K, act, mask_first, ntiles;
+    // WIN: a stride-1 conv whose tap row is a contiguous window of the NHWC input (TS * Cin elements, a multiple of
+    // 32: the space-to-depth stem, 4 taps x 16 channels): reduction step cs = (tap row a, 32-element piece h of its
+    // window), C = TR * TS * Cin "virtual" channels in the weights' own [K][tap][Cin] order
+    int Cin, H, W, pad_t, pad_l, spr;   // spr = reduction steps per tap row
+    FastDiv dHW, dW;
 };
 
-template <int CS, int PT>
+template <int CS, int PT, bool WIN = false>
 __global__ __launch_bounds__(256) void conv_pw_stream_kernel(const PwStream S) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CP = CS * 32 + 8;                     // LDS row of a weight row (elements): 16-B aligned, banks staggered
@@ -886,6 +891,21 @@ __global__ __launch_bounds__(256) void conv_pw_stream_kernel(const PwStream S) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const int m = m0 + pt * 16 + p;
+            if (WIN) {
+                const int mc = min(m, S.M - 1);
+                const int n = (int)fdiv((unsigned)mc, S.dHW), rem = mc - n * S.H * S.W;
+                const int py = (int)fdiv((unsigned)rem, S.dW), px = rem - py * S.W;
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) {
+                    const int a = cs / S.spr, e = (cs - a * S.spr) * 32 + 8 * g;
+                    const int b = e / S.Cin, ch = e - b * S.Cin;
+                    const int r = py + a - S.pad_t, col = px + b - S.pad_l;
+                    xf[pt][cs] = (s8v){0, 0, 0, 0, 0, 0, 0, 0};
+                    if (m < S.M && (unsigned)r < (unsigned)S.H && (unsigned)col < (unsigned)S.W)
+                        xf[pt][cs] = *reinterpret_cast<const s8v*>(S.x + (((long long)n * S.H + r) * S.W + col) * S.Cin + ch);
+                }
+                continue;
+            }
 #pragma unroll
             for (int cs = 0; cs < CS; ++cs) {
                 const int c = cs * 32 + 8 * g;
@@ -945,17 +965,18 @@ __global__ __launch_bounds__(256) void conv_pw_stream_kernel(const PwStream S) {
     }
 }
 
-template <int CS, int PT>
+template <int CS, int PT, bool WIN = false>
 static void pw_stream_launch(const PwStream& S, int lds, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_pw_stream_kernel<CS, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void*)conv_pw_stream_kernel<CS, PT, WIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr = true;
     }
-    const int per_cu = lds <= 16384 ? 6 : (lds <= 32768 ? 4 : 2);
+    int per_cu = (160 * 1024 - 4096) / (lds + 256);        // blocks of one CU by LDS (160 KiB), at most 6
+    per_cu = per_cu > 6 ? 6 : (per_cu < 1 ? 1 : per_cu);
     const int nb = (S.ntiles + 3) / 4;
     const int grid = nb < 256 * per_cu ? nb : 256 * per_cu;
-    hipLaunchKernelGGL((conv_pw_stream_kernel<CS, PT>), dim3((unsigned)grid), dim3(256), lds, st, S);
+    hipLaunchKernelGGL((conv_pw_stream_kernel<CS, PT, WIN>), dim3((unsigned)grid), dim3(256), lds, st, S);
 }
 
 }  // namespace
@@ -984,6 +1005,48 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     //      tiled kernels, 2 wherever it applies)
     const char* pw_env = getenv("MI355_PW_STREAM");         // (read per call: the tests switch it)
     const int pw_mode = pw_env ? atoi(pw_env) : 1;
+    if (pw_mode > 0 && in.nprob == 1 && ksplit == 1 && in.T > 1 && !in.out_f32 && in.K % 8 == 0 && C <= 32) {
+        // window form: the space-to-depth stem (4 x 4 taps over 16 channels, stride 1): 79 -> 68 us at 16 x 256 x 256 (two
+        // pixel rows per wave instead of one: 81 us, the registers cost a wave per SIMD)
+        const Mi355ConvProblem& s = in.prob[0];
+        const long long PQ = (long long)s.P * s.Q, M = (long long)s.N * PQ;
+        const int CS = (in.T * C + 31) / 32, KP = (in.K + 31) & ~31;
+        const int lds = KP * (CS * 32 + 8) * 2 + KP * 4;
+        const bool ok =
+            s.TR * s.TS == in.T && (s.TS * C) % 32 == 0 && CS <= 8 && s.sh == 1 && s.sw == 1 && s.dhs == 1 && s.dws == 1 &&
+            s.r0 == 0 && s.rs == 1 && s.s0 == 0 && s.ss == 1 && s.S == s.TS && s.P == s.H && s.Q == s.W &&
+            (s.in_sN == 0 || s.in_sN == (long long)s.H * s.W * C) && s.in && s.out && s.N > 0 && PQ > 0 &&
+            s.out_mh == 1 && s.out_mw == 1 && s.out_oh == 0 && s.out_ow == 0 && s.out_sW >= in.K && s.out_sW % 8 == 0 &&
+            s.out_sH == s.Q * s.out_sW && s.out_sN == PQ * s.out_sW && !s.addend && !s.mask &&
+            (((uintptr_t)s.in | (uintptr_t)s.out) & 15) == 0 && M < 0x7fffffffLL && lds <= 65536;
+        if (ok && (pw_mode > 1 || (M >= 131072 && in.K <= 144))) {
+            PwStream S;
+            memset(&S, 0, sizeof(S));
+            S.x = (const unsigned short*)s.in;
+            S.w = (const unsigned short*)(s.weight ? s.weight : in.weight);
+            S.bias = s.weight ? s.bias : in.bias;
+            S.out = (unsigned short*)s.out;
+            S.out_row = s.out_sW;
+            S.M = (int)M;  S.C = in.T * C;  S.K = in.K;  S.act = in.act;
+            S.Cin = C;  S.H = s.H;  S.W = s.W;  S.pad_t = -s.dh0;  S.pad_l = -s.dw0;  S.spr = s.TS * C / 32;
+            S.dHW = make_fastdiv((unsigned)(s.H * s.W));  S.dW = make_fastdiv((unsigned)s.W);
+            MI355_REQUIRE(((uintptr_t)S.w & 15) == 0, "conv_gather: weight alignment");
+            const int pt = CS <= 2 ? 4 : (CS <= 4 ? 2 : 1);
+            S.ntiles = (int)cdiv(M, 16 * pt);
+            hipStream_t st = (hipStream_t)stream;
+            switch (CS) {
+                case 1: pw_stream_launch<1, 4, true>(S, lds, st); break;
+                case 2: pw_stream_launch<2, 4, true>(S, lds, st); break;
+                case 3: pw_stream_launch<3, 2, true>(S, lds, st); break;
+                case 4: pw_stream_launch<4, 2, true>(S, lds, st); break;
+                case 5: pw_stream_launch<5, 1, true>(S, lds, st); break;
+                case 6: pw_stream_launch<6, 1, true>(S, lds, st); break;
+                case 7: pw_stream_launch<7, 1, true>(S, lds, st); break;
+                default: pw_stream_launch<8, 1, true>(S, lds, st); break;
+            }
+            return check_launch("conv_pw_stream_kernel<window>");
+        }
+    }
     if (pw_mode > 0 && in.nprob == 1 && ksplit == 1 && in.T == 1 && !in.out_f32 && in.K % 8 == 0 && C <= 256) {
         const Mi355ConvProblem& s = in.prob[0];
         const long long PQ = (long long)s.P * s.Q, M = (long long)s.N * PQ;
@@ -1007,6 +1070,7 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         const bool wins = C % 64 != 0 && ((M >= 131072 && in.K <= 144) || (M >= 65536 && C >= 96 && in.K <= 48));
         if (dense && (pw_mode > 1 || wins)) {
             PwStream S;
+            memset(&S, 0, sizeof(S));
             S.x = (const unsigned short*)s.in;
             S.w = (const unsigned short*)(s.weight ? s.weight : in.weight);
             S.bias = s.weight ? s.bias : in.bias;

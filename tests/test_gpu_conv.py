@@ -121,6 +121,35 @@ def test_pointwise_stream_kernel(dev, case, mode, monkeypatch):
         _close(o2.permute(0, 3, 1, 2), want, 1e-2)
 
 
+@pytest.mark.parametrize('case', [(2, 37, 41, 16, 64, 4, 4, 2, 2), (1, 64, 48, 16, 24, 4, 4, 2, 2), (2, 19, 23, 16, 40, 2, 2, 1, 0),
+                                  (1, 30, 33, 32, 72, 3, 1, 1, 0), (3, 9, 11, 8, 16, 2, 4, 0, 2), (1, 21, 17, 16, 64, 3, 2, 1, 1)])
+def test_window_stream_kernel(dev, case, monkeypatch):
+    """The window form of conv_pw_stream_kernel: stride-1 convs over few channels whose tap row is a contiguous
+    TS * C window of the NHWC input (the space-to-depth stem: 4 x 4 taps over 16 channels, pad 2 before / 1 after),
+    forced with MI355_PW_STREAM=2, against torch on the explicitly padded input."""
+    from objectdetection.pytorch_amd import ops_conv
+    monkeypatch.setenv('MI355_PW_STREAM', '2')
+    N, H, W, C, K, R, S, pt, pl = case
+    x = _mk((N, C, H, W), 31)
+    w = _mk((K, C, R, S), 32, scale=(2.0 / (C * R * S)) ** 0.5)
+    b = _mk((K,), 33).float()
+    ref = F.relu(F.conv2d(F.pad(x, (pl, S - 1 - pl, pt, R - 1 - pt)), w, b))
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last)
+    w_fwd = torch.zeros((K, R * S, C), dtype=torch.bfloat16, device=dev)
+    w_dgr = torch.zeros((C, R * S, (K + 7) // 8 * 8), dtype=torch.bfloat16, device=dev)
+    ops_conv.prep_weight(wd, C, None, w_fwd, w_dgr)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    out = torch.empty((N, H, W, K), dtype=torch.bfloat16, device=dev)
+    pr = ops_conv.fwd_problem(xh, out.data_ptr(), R, S, 1, (pt, pl), K=K, out_size=(H, W))
+    ops_conv.launch_gather([pr], w_fwd, K, R * S, xh, bias=b.to(dev), act=ops_conv.ACT_RELU)
+    _close(out.permute(0, 3, 1, 2), ref, 1e-2)
+    monkeypatch.setenv('MI355_PW_STREAM', '0')          # the tiled kernels on the same launch: same result up to bf16
+    out0 = torch.empty_like(out)
+    pr = ops_conv.fwd_problem(xh, out0.data_ptr(), R, S, 1, (pt, pl), K=K, out_size=(H, W))
+    ops_conv.launch_gather([pr], w_fwd, K, R * S, xh, bias=b.to(dev), act=ops_conv.ACT_RELU)
+    _close(out0.permute(0, 3, 1, 2), ref, 1e-2)
+
+
 @pytest.mark.parametrize('case,ksplit', [((1, 4, 4, 2048, 256, 3, 2, 1), 16), ((2, 9, 7, 512, 192, 3, 1, 1), 3),
                                          ((2, 6, 5, 1024, 36, 1, 1, 0), 4)])
 def test_conv_fwd_splitk(dev, case, ksplit):
