@@ -152,7 +152,9 @@ typedef struct Mi355LayerDesc {
     float eps;
     int32_t atomic;          /* grads: 1 = another descriptor writes the same dW / dbias (weights shared across pyramid
                                 levels) and the additions are fp32 atomics; 2 = this descriptor is a non-head member of
-                                a share_next chain: its dW / shared-bias contribution is added by the chain's head */
+                                a share_next chain: its dW / shared-bias contribution is added by the chain's head;
+                                3 = the only writer of its dW / dgamma / dbeta / dbias in this step: plain stores, the
+                                caller need not zero them (0: += into zeroed gradients) */
     int32_t nslabs;          /* grads: G / colsum hold this many split-K slabs (0 or 1: a single buffer) */
     int32_t f32_shadows;     /* prep: != 0 writes w_fwd / w_dgr as fp32 (the fp32-accurate mode) instead of bf16 */
     int32_t share_next;      /* grads: 1-based table index of the next descriptor that writes the same dW (same K, C,

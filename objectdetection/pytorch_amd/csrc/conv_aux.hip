@@ -618,6 +618,7 @@ __global__ __launch_bounds__(256) void param_grads_table_kernel(const Mi355Layer
     const int T = d.R * d.S;
     const float sck = pg_scale(d, k);
     const bool member = d.atomic == 2;
+    const bool ow = d.atomic == 3;                     // sole writer of its gradients this step: store, do not add
     float dot = 0.0f;
     const int total = T * d.Cpad;
     // 16-B slab reads (Cpad % 8 == 0, rows and slabs 16-B aligned).  A row of few pieces (EfficientDet's 1x1 convs:
@@ -682,7 +683,9 @@ __global__ __launch_bounds__(256) void param_grads_table_kernel(const Mi355Layer
                     for (int e = 0; e < 4; ++e) {
                         if (c0 + e >= d.C) continue;
                         const long long wo = k * d.sk + (c0 + e) * d.sc + r * d.sr + sx * d.ss;
-                        if (d.atomic) atomicAdd(d.dW + wo, oe[e]); else d.dW[wo] += oe[e];
+                        if (d.atomic == 1) atomicAdd(d.dW + wo, oe[e]);
+                        else if (ow) d.dW[wo] = oe[e];
+                        else d.dW[wo] += oe[e];
                     }
                 }
             }
@@ -712,13 +715,22 @@ __global__ __launch_bounds__(256) void param_grads_table_kernel(const Mi355Layer
             if (d.dgamma) {
                 const float invstd = 1.0f / sqrtf(d.var[k] + d.eps);
                 const float mu = d.mean[k] - (d.conv_bias ? d.conv_bias[k] : 0.0f);
-                d.dgamma[k] += invstd * ((red[0] + red[1] + red[2] + red[3]) - mu * cs);
+                const float dg = invstd * ((red[0] + red[1] + red[2] + red[3]) - mu * cs);
+                if (ow) d.dgamma[k] = dg; else d.dgamma[k] += dg;
             }
             if (d.dbeta) {
-                if (!beta_shared) d.dbeta[k] += cs;
-                else if (!member) { if (d.atomic) atomicAdd(d.dbeta + k, bsum); else d.dbeta[k] += bsum; }
+                if (!beta_shared) { if (ow) d.dbeta[k] = cs; else d.dbeta[k] += cs; }
+                else if (!member) {
+                    if (d.atomic == 1) atomicAdd(d.dbeta + k, bsum);
+                    else if (ow) d.dbeta[k] = bsum;
+                    else d.dbeta[k] += bsum;
+                }
             }
-            if (d.dconv_bias && !member) { if (d.atomic) atomicAdd(d.dconv_bias + k, csum); else d.dconv_bias[k] += csum; }
+            if (d.dconv_bias && !member) {
+                if (d.atomic == 1) atomicAdd(d.dconv_bias + k, csum);
+                else if (ow) d.dconv_bias[k] = csum;
+                else d.dconv_bias[k] += csum;
+            }
         }
     }
 }

@@ -955,6 +955,10 @@ class RetinaPlan(object):
                         descs[prev].share_next = len(descs)          # 1-based index of this descriptor
                         d.atomic = 2
                     chain_tail[id(s.conv)] = len(descs) - 1
+            if self._overwrite_grads():
+                for d in descs:
+                    if d.atomic == 0 and d.dW != self._stem_dwp_ptr():
+                        d.atomic = 3                   # sole writer: plain stores (begin_backward zeroes only the gaps)
             tab = (ops_conv.upload_table(descs, self.dev), len(descs), nb) if descs else None
             self.pgrad_tables[key] = tab or ()
         if not tab:
@@ -1039,6 +1043,51 @@ class RetinaPlan(object):
                   ptr(self.loss_ws), c_i64(self.loss_ws_bytes), c_vp(self._stream()))
         return self.losses
 
+    def _stem_dwp_ptr(self):
+        return self.stem_dwp.data_ptr() if getattr(self, 'stem_s2d', False) else -1
+
+    def _overwrite_grads(self):
+        """The parameter-gradient tables STORE a layer's gradients instead of adding to a zeroed arena (0.3 GB less
+        traffic per RetinaNet-R50 step: the 145 MB memset and the read half of the read-modify-write).  Only where every
+        descriptor is the sole writer of its tensors: the plain RetinaNet plan in slab mode (no shared-conv chains, no
+        atomics, no extra tables).  MI355_PG_OVERWRITE=0 disables it."""
+        if '_ow' not in self.__dict__:
+            seen = {}
+            for s in self.pgrad_specs:
+                seen[id(s.conv)] = seen.get(id(s.conv), 0) + 1
+            self._ow = (type(self) is RetinaPlan and self.deterministic and bool(self.pgrad_specs) and
+                        all(v == 1 for v in seen.values()) and os.environ.get('MI355_PG_OVERWRITE', '1') == '1')
+        return self._ow
+
+    def _zero_gaps(self, arena):
+        """Overwrite mode: the arena ranges NO table descriptor stores (frozen / unused parameters, alignment, the
+        space-to-depth stem's weight whose gradient is added by the unpack launch), merged; zeroed per backward."""
+        cache = self.__dict__.setdefault('_gap_cache', {})
+        if arena not in cache:
+            self._carve_grads(arena)
+            base, cov = self.grad_arenas[arena].data_ptr(), []
+            for s in self.pgrad_specs:
+                d = self._layer_desc(s, arena)
+                if d.dW == self._stem_dwp_ptr():       # (this descriptor keeps adding: all of its targets are gaps)
+                    continue
+                if d.dW:
+                    cov.append(((d.dW - base) // 4, s.conv.weight.numel()))
+                for q in (d.dgamma, d.dbeta, d.dconv_bias):
+                    if q:
+                        cov.append(((q - base) // 4, s.K))
+            cov.sort()
+            gaps, pos = [], 0
+            for lo, n in cov:
+                assert 0 <= lo and lo + n <= self.grad_numel and lo >= pos, 'overlapping gradient targets'
+                if lo > pos:
+                    gaps.append((pos, lo))
+                pos = lo + n
+            if pos < self.grad_arenas[arena].numel():
+                gaps.append((pos, self.grad_arenas[arena].numel()))
+            cache[arena] = [self.grad_arenas[arena][lo:hi] for lo, hi in gaps]
+        for view in cache[arena]:
+            view.zero_()
+
     def begin_backward(self, g_cls, g_reg):
         """Zero the gradient arena, loss backward (d loss / d head outputs).  Returns the arena index."""
         st = self._stream()
@@ -1051,7 +1100,10 @@ class RetinaPlan(object):
         else:
             gl[0:1].copy_(g_cls.reshape(1) if g_cls is not None else torch.zeros(1, device=self.dev))
             gl[1:2].copy_(g_reg.reshape(1) if g_reg is not None else torch.zeros(1, device=self.dev))
-        self.grad_arenas[arena].zero_()
+        if self._overwrite_grads():
+            self._zero_gaps(arena)
+        else:
+            self.grad_arenas[arena].zero_()
         if self.scratch.numel() > 1:                   # (atomic mode's raw gradients; the slab mode has none)
             self.scratch.zero_()
         if getattr(self, 'stem_s2d', False):
