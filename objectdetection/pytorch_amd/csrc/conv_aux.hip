@@ -658,9 +658,15 @@ __global__ __launch_bounds__(256) void param_grads_table_kernel(const Mi355Layer
                 c0 = i4 - t * d.Cpad;
                 r = t / d.S; sx = t - r * d.S;
                 if (d.dgamma) {
+                    const float* wp = d.w + (k * d.sk + c0 * d.sc + r * d.sr + sx * d.ss);
+                    if (d.sc == 1 && c0 + 4 <= d.C && ((uintptr_t)wp & 15) == 0) {      // channel-contiguous weights: 16 B
+                        const float4 w4 = *reinterpret_cast<const float4*>(wp);
+                        dp += w4.x * ge[0];  dp += w4.y * ge[1];  dp += w4.z * ge[2];  dp += w4.w * ge[3];
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (c0 + e < d.C) dp += d.w[k * d.sk + (c0 + e) * d.sc + r * d.sr + sx * d.ss] * ge[e];
+                        for (int e = 0; e < 4; ++e)
+                            if (c0 + e < d.C) dp += wp[e * d.sc] * ge[e];
+                    }
                 }
             }
             if (parts > 1) {                               // (uniform)
@@ -679,13 +685,18 @@ __global__ __launch_bounds__(256) void param_grads_table_kernel(const Mi355Layer
             if (part == 0 && act) {
                 dot += dp;
                 if (!member) {
+                    float* gp = d.dW + (k * d.sk + c0 * d.sc + r * d.sr + sx * d.ss);
+                    if (ow && d.sc == 1 && c0 + 4 <= d.C && ((uintptr_t)gp & 15) == 0) {
+                        *reinterpret_cast<float4*>(gp) = make_float4(oe[0], oe[1], oe[2], oe[3]);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (c0 + e >= d.C) continue;
-                        const long long wo = k * d.sk + (c0 + e) * d.sc + r * d.sr + sx * d.ss;
-                        if (d.atomic == 1) atomicAdd(d.dW + wo, oe[e]);
-                        else if (ow) d.dW[wo] = oe[e];
-                        else d.dW[wo] += oe[e];
+                        for (int e = 0; e < 4; ++e) {
+                            if (c0 + e >= d.C) continue;
+                            float* q = gp + e * d.sc;
+                            if (d.atomic == 1) atomicAdd(q, oe[e]);
+                            else if (ow) *q = oe[e];
+                            else *q += oe[e];
+                        }
                     }
                 }
             }
