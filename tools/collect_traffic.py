@@ -35,7 +35,7 @@ def main():
         wr = w.get(k, [0, 0.0])[1] * 1024 / steps
         kern[k[:96]] = {'launches_per_step': round(f[k][0] / steps, 2), 'read_bytes_per_step': round(rd),
                         'write_bytes_per_step': round(wr)}
-    conv = {k: v for k, v in kern.items() if 'conv_gather' in k or 'conv_wgrad' in k or 'splitk_finish' in k}
+    conv = {k: v for k, v in kern.items() if 'conv_gather' in k or 'conv_wgrad' in k or 'splitk_finish' in k or 'conv_pw_stream' in k}
     tot = sum(v['read_bytes_per_step'] + v['write_bytes_per_step'] for v in conv.values())
     n = sum(v['launches_per_step'] for v in conv.values())
     res = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), %d steps' % steps,
