@@ -506,17 +506,20 @@ __device__ __forceinline__ int find_layer(const Mi355LayerDesc* __restrict__ t, 
     return lo;
 }
 
+// One block = one (tap, 32 k, 64 c) tile: two channels per thread (8-B reads where the master weights are
+// channel-contiguous, 4-B bf16 pair stores), half the blocks of the 32 x 32 form and twice the bytes behind each
+// block's descriptor lookup.
 __global__ __launch_bounds__(256) void prep_weights_table_kernel(const Mi355LayerDesc* __restrict__ table,
                                                                  int nlayers) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[32][65];
     __shared__ float s_scale[32];
     const Mi355LayerDesc d = table[find_layer(table, nlayers, blockIdx.x)];
     int b = blockIdx.x - d.block_begin;
-    const int ct = (d.Cpad + 31) / 32, kt = (d.Kpad + 31) / 32;
+    const int ct = (d.Cpad + 63) / 64, kt = (d.Kpad + 31) / 32;
     const int c_tile = b % ct;  b /= ct;
     const int k_tile = b % kt;  b /= kt;
     const int rs = b, T = d.R * d.S, r = rs / d.S, s = rs - r * d.S;
-    const int k0 = k_tile * 32, c0 = c_tile * 32;
+    const int k0 = k_tile * 32, c0 = c_tile * 64;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     if (threadIdx.x < 32) {
         const int k = k0 + threadIdx.x;
@@ -535,18 +538,30 @@ __global__ __launch_bounds__(256) void prep_weights_table_kernel(const Mi355Laye
     unsigned short* w_dgr = (unsigned short*)d.w_dgr;
     const bool f32 = d.f32_shadows != 0;               // fp32-accurate mode: the shadows stay fp32
     for (int j = ty; j < 32; j += 8) {
-        const int k = k0 + j, c = c0 + tx;
-        float v = 0.0f;
-        if (k < d.K && c < d.C) v = d.w[k * d.sk + c * d.sc + r * d.sr + s * d.ss] * s_scale[j];
-        tile[j][tx] = v;
-        if (k < d.K && c < d.Cpad) {
-            if (f32) ((float*)d.w_fwd)[((long long)k * T + rs) * d.Cpad + c] = v;
-            else w_fwd[((long long)k * T + rs) * d.Cpad + c] = f32_to_bf16_rn(v);
+        const int k = k0 + j, c = c0 + 2 * tx;
+        float v0 = 0.0f, v1 = 0.0f;
+        if (k < d.K && c < d.C) {
+            const float* wp = d.w + (k * d.sk + c * d.sc + r * d.sr + s * d.ss);
+            if (d.sc == 1 && c + 1 < d.C && ((uintptr_t)wp & 7) == 0) {
+                const float2 q = *reinterpret_cast<const float2*>(wp);
+                v0 = q.x;  v1 = q.y;
+            } else {
+                v0 = wp[0];
+                if (c + 1 < d.C) v1 = wp[d.sc];
+            }
+            v0 *= s_scale[j];  v1 *= s_scale[j];
+        }
+        tile[j][2 * tx] = v0;
+        tile[j][2 * tx + 1] = v1;
+        if (k < d.K && c < d.Cpad) {                   // (Cpad % 8 == 0: c + 1 < Cpad too, the pair is 4-B aligned)
+            const long long o = ((long long)k * T + rs) * d.Cpad + c;
+            if (f32) { ((float*)d.w_fwd)[o] = v0;  ((float*)d.w_fwd)[o + 1] = v1; }
+            else *reinterpret_cast<unsigned*>(w_fwd + o) = (unsigned)f32_to_bf16_rn(v0) | ((unsigned)f32_to_bf16_rn(v1) << 16);
         }
     }
     __syncthreads();
     if (w_dgr) {
-        for (int j = ty; j < 32; j += 8) {
+        for (int j = ty; j < 64; j += 8) {
             const int c = c0 + j, k = k0 + tx;
             if (c < d.C && k < d.Kpad) {
                 if (f32) ((float*)d.w_dgr)[((long long)c * T + rs) * d.Kpad + k] = tile[tx][j];

@@ -414,7 +414,7 @@ class RetinaPlan(object):
         for s in self.specs:
             d = self._layer_desc(s)
             d.block_begin = nb
-            nb += (-(-s.Cpad // 32)) * (-(-s.Kpad // 32)) * s.R * s.S
+            nb += (-(-s.Cpad // 64)) * (-(-s.Kpad // 32)) * s.R * s.S      # blocks of (tap, 32 k, 64 c), as the kernel counts them
             descs.append(d)
         self.prep_table = ops_conv.upload_table(descs, self.dev)
         self.bufs.append(self.prep_table)
