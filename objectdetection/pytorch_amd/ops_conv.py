@@ -184,10 +184,14 @@ def pick_split_rows(total_rows, tiles_per_chunk, target_blocks=512, min_rows=512
     groups, MI355_WG_GROUPS=2 + granule 128, halves the slabs but runs 2 % slower end to end.)"""
     chunks = max(1, target_blocks // max(1, tiles_per_chunk))
     rows = -(-total_rows // chunks)
-    if tiles_per_chunk * -(-total_rows // min_rows) < 256:
-        # the floor would leave CUs without a block (EfficientDet's 1x1 convs: one 64x64 tile, 64 chunks of
-        # 1024 rows on 256 CUs): relax it to 256 rows / one block per CU, whichever comes first
-        min_rows = max(256, min(min_rows, -(-total_rows * tiles_per_chunk // 256)))
+    import os
+    relax_blocks = int(os.environ.get('MI355_WG_RELAX_BLOCKS', '128'))
+    if tiles_per_chunk * -(-total_rows // min_rows) < relax_blocks:
+        # the floor would leave most CUs without a block (EfficientDet's 1x1 convs: one 64x64 tile, 64 chunks of
+        # 1024 rows on 256 CUs): relax it to 256 rows / one block per TWO CUs, whichever comes first (one block per CU
+        # wrote twice the slabs for launches that are latency-bound either way: D0 2 208 -> 2 222 img/s; no relaxing at
+        # all: 2 177)
+        min_rows = max(256, min(min_rows, -(-total_rows * tiles_per_chunk // max(relax_blocks, 1))))
         min_rows = -(-min_rows // granule) * granule
     rows = max(min_rows, -(-rows // granule) * granule)
     return rows

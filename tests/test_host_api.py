@@ -121,7 +121,7 @@ def test_wgrad_split_rows_are_whole_granules():
             for floor in (512, 1024):
                 rows = pick_split_rows(total, tiles, 512, floor, 64)
                 assert rows % 64 == 0 and rows >= 256, (total, tiles, floor, rows)
-    assert pick_split_rows(16 * 64 * 64, 1, 512, 1024, 64) == 256        # one small tile: a block per CU
+    assert pick_split_rows(16 * 64 * 64, 1, 512, 1024, 64) == 512        # one small tile: a block per two CUs (128 blocks)
     assert pick_split_rows(16 * 32 * 32, 16, 512, 1024, 64) == 1024       # enough tiles: the floor stands
 
 
