@@ -47,6 +47,12 @@ int mi355_adamw_flat_masked(float* param, float* grad, float* m, float* v, int64
                             float beta2, float eps, float weight_decay, const void* state, int scale_grad,
                             const int64_t* skip_ranges, int nskip, void* stream);
 
+/* The masked update with the hyper-parameters read from DEVICE memory: hyper = float[5] {lr, beta1, beta2, eps,
+ * weight_decay}.  For a launch captured in a hipGraph: by-value kernel arguments are frozen at capture, so a
+ * ReduceLROnPlateau step (train.py:268, :346) between replays would be ignored; the host refreshes this vector. */
+int mi355_adamw_flat_hyper(float* param, float* grad, float* m, float* v, int64_t n, const float* hyper,
+                           const void* state, int scale_grad, const int64_t* skip_ranges, int nskip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

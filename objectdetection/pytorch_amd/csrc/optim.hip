@@ -97,9 +97,13 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float4* __restrict__ p,
                                                          float4* __restrict__ m, float4* __restrict__ v,
                                                          long long n4, float lr, float b1, float b2, float eps,
                                                          float wd, const OptState* __restrict__ st, int scale_grad,
-                                                         const long long* __restrict__ skip, int nskip) {
+                                                         const long long* __restrict__ skip, int nskip,
+                                                         const float* __restrict__ hyper) {
     const OptState s = *st;
     if (s.skip != 0.0f) return;
+    if (hyper) {                       // device-resident hyper-parameters (a captured launch follows an LR scheduler)
+        lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4];
+    }
     const float bc1 = 1.0f - powf(b1, (float)s.step);
     const float bc2s = sqrtf(1.0f - powf(b2, (float)s.step));
     const float step_size = lr / bc1;
@@ -131,9 +135,9 @@ extern "C" int mi355_adamw_flat(float* param, float* grad, float* m, float* v, i
                                    nullptr, 0, stream);
 }
 
-extern "C" int mi355_adamw_flat_masked(float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1,
-                                       float beta2, float eps, float weight_decay, const void* state, int scale_grad,
-                                       const int64_t* skip_ranges, int nskip, void* stream) {
+static int adamw_launch(float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, const void* state, int scale_grad, const int64_t* skip_ranges,
+                        int nskip, const float* hyper, void* stream) {
     MI355_REQUIRE(nskip == 0 || skip_ranges, "adamw_flat: null skip table");
     MI355_REQUIRE(param && grad && m && v && state && n > 0, "adamw_flat: null pointer");
     MI355_REQUIRE((n & 3) == 0, "adamw_flat: arena length must be a multiple of 4 (pad the arena)");
@@ -143,6 +147,20 @@ extern "C" int mi355_adamw_flat_masked(float* param, float* grad, float* m, floa
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (float4*)param, (float4*)grad, (float4*)m, (float4*)v, n4, lr, beta1, beta2, eps,
-                       weight_decay, (const OptState*)state, scale_grad, (const long long*)skip_ranges, nskip);
+                       weight_decay, (const OptState*)state, scale_grad, (const long long*)skip_ranges, nskip, hyper);
     return check_launch("adamw_flat_kernel");
+}
+
+extern "C" int mi355_adamw_flat_masked(float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                                       float beta2, float eps, float weight_decay, const void* state, int scale_grad,
+                                       const int64_t* skip_ranges, int nskip, void* stream) {
+    return adamw_launch(param, grad, m, v, n, lr, beta1, beta2, eps, weight_decay, state, scale_grad, skip_ranges, nskip,
+                        nullptr, stream);
+}
+
+extern "C" int mi355_adamw_flat_hyper(float* param, float* grad, float* m, float* v, int64_t n, const float* hyper,
+                                      const void* state, int scale_grad, const int64_t* skip_ranges, int nskip,
+                                      void* stream) {
+    MI355_REQUIRE(hyper, "adamw_flat_hyper: null hyper-parameter vector");
+    return adamw_launch(param, grad, m, v, n, 0.f, 0.f, 0.f, 0.f, 0.f, state, scale_grad, skip_ranges, nskip, hyper, stream);
 }

@@ -15,6 +15,7 @@ Mirrors the forward of architectures/retinanet.py:272-295 and its autograd backw
 """
 import ctypes
 import os
+import struct
 
 import torch
 
@@ -26,6 +27,52 @@ from .ops_conv import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvLaunch, dgrad_proble
 
 def _ceil8(v):
     return (v + 7) // 8 * 8
+
+
+# ---------------------------------------------------------------------------------------------- plan tables
+PLAN_MAX_ARGS = 24                       # include/mi355det_plan.h
+PLAN_MAIN, PLAN_SIDE, PLAN_SIDE_RR = 0, 1, 2
+
+
+class PlanStep(ctypes.Structure):
+    """Mi355PlanStep."""
+    _fields_ = [('fn', ctypes.c_int32), ('where', ctypes.c_int32), ('host', ctypes.c_int32), ('nargs', ctypes.c_int32),
+                ('arg', ctypes.c_uint64 * PLAN_MAX_ARGS)]
+
+
+class PlanState(ctypes.Structure):
+    """Mi355PlanState."""
+    _fields_ = [('next', ctypes.c_int32), ('failed', ctypes.c_int32), ('side_dirty', ctypes.c_int32),
+                ('side2_dirty', ctypes.c_int32), ('rr', ctypes.c_int32), ('forks', ctypes.c_int32),
+                ('reserved', ctypes.c_int32 * 2)]
+
+
+_BYREF = type(ctypes.byref(ctypes.c_int()))
+_M64 = (1 << 64) - 1
+
+
+def _slot(a):
+    """The 8-byte argument slot of one ctypes argument of a step (low bytes = the value, as the C side reads it with
+    the parameter's own type)."""
+    if a is None:
+        return 0
+    if isinstance(a, ctypes.c_void_p):
+        return a.value or 0
+    if isinstance(a, (ctypes.c_int, ctypes.c_int64, ctypes.c_uint, ctypes.c_uint64)):
+        return a.value & _M64
+    if isinstance(a, ctypes.c_float):
+        return struct.unpack('<I', struct.pack('<f', a.value))[0]
+    if isinstance(a, ctypes.c_double):
+        return struct.unpack('<Q', struct.pack('<d', a.value))[0]
+    if isinstance(a, _BYREF):
+        return ctypes.addressof(a._obj)
+    if isinstance(a, (ctypes.Array, ctypes.Structure)):
+        return ctypes.addressof(a)
+    if isinstance(a, ctypes._Pointer):
+        return ctypes.cast(a, ctypes.c_void_p).value or 0
+    if isinstance(a, int):
+        return a & _M64
+    raise TypeError('cannot marshal %r into a plan step' % (a,))
 
 
 class LayerSpec(object):
@@ -124,8 +171,8 @@ class RetinaPlan(object):
         # MI355_SIDE_STREAMS=2: the weight-gradient launches alternate between TWO side streams (two independent
         # latency-bound backbone wgrads in flight beside the data-gradient chain)
         self.n_side = max(1, int(os.environ.get('MI355_SIDE_STREAMS', '1')))
-        self._side2, self._side_rr = None, 0
-        self._side, self._side_dirty = None, False
+        self._side, self._side2 = None, None
+        self._pstate = PlanState()
         self._side_ids, self._mark_side = set(), False
         self.last_arena = 0
         # one forward, one backward: the activations / assignment state of the LAST forward live in this plan's
@@ -185,54 +232,107 @@ class RetinaPlan(object):
 
     SIDE_STEPS = ('mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_slabs_f32', 'mi355_conv_wgrad_multi')
 
-    def _run(self, steps, stream):
-        """Launch `steps` on `stream`.  With the side stream enabled (MI355_SIDE_STREAM=1) the weight-gradient
-        launches go to a second HIP stream, forked behind everything issued so far: a wgrad and the data
-        gradient of the same layer only share inputs, so they run concurrently and fill each other's
-        ramp-up / tail; `join_side()` is the fence in front of the consumers of dW."""
-        s = c_vp(stream)
-        # (not while a hipGraph is being captured: a branched graph replayed slower than the single-stream one
-        # and one replay disagreed with the eager schedule; graphs keep the single-stream order)
-        side = self._side_stream() if (self.use_side and not torch.cuda.is_current_stream_capturing()) else None
-        fork = self.lib.mi355_stream_fork
-        for fn, args, name in steps:
-            if name.startswith('py:'):                       # host-side step (BN statistics all-reduce), main stream
-                fn(stream)
+    # ------------------------------------------------------------------ replay (include/mi355det_plan.h)
+    # A step list is marshalled ONCE into a table of 8-byte argument slots (`PlanStep`); `mi355_plan_run` enqueues a
+    # range of it below Python: one ctypes call per range instead of one per launch plus one per fork edge (the
+    # Python loop it replaces cost ~20 us per launch: 7.9 ms of host time per 10 ms RetinaNet-R50 step).  Which steps
+    # go to the side stream is part of the TABLE (`where`), and the runner issues a fork edge in front of a side step
+    # whenever the main stream has received work since the last one: the dependency edges of a replay do not depend
+    # on host-side flags, so an eager replay and a hipGraph capture of the same table have the same edges.
+    def _compiled(self, steps):
+        cache = self.__dict__.setdefault('_tables', {})
+        key = id(steps)
+        ent = cache.get(key)
+        if ent is not None and ent[1] == len(steps) and ent[3] is steps:
+            return ent
+        n = len(steps)
+        arr = (PlanStep * max(n, 1))()
+        lookup, arity = self.lib.mi355_plan_lookup, self.lib.mi355_plan_arity
+        for i, (fn, args, name) in enumerate(steps):
+            st = arr[i]
+            if name.startswith('py:'):                         # host-side step (BN statistics all-reduce)
+                st.host, st.fn = 1, -1
                 continue
-            if side is not None and (name in self.SIDE_STEPS or id(args) in self._side_ids):
-                tgt = side
-                if self.n_side > 1 and name in self.SIDE_STEPS:
-                    self._side_rr += 1
-                    if self._side_rr & 1:
-                        if self._side2 is None:
-                            self._side2 = torch.cuda.Stream(device=self.dev)
-                        tgt = self._side2
-                        self._side2_dirty = True
-                ss = c_vp(tgt.cuda_stream)
-                rc = fork(s, ss) or fn(*args, ss)            # side stream ordered behind main's launches so far
-                self._side_dirty = True
-            else:
-                rc = fn(*args, s)
-            if rc:
-                raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, self.lib.mi355_last_error().decode()))
+            if fn is None:
+                raise _lib.Mi355Error('unknown deferred step %r' % (name,))
+            idx = lookup(name.encode())
+            if idx < 0:
+                raise _lib.Mi355Error('%s is not a stream-taking entry point of include/*.h (tools/gen_plan_table.py)' % name)
+            if len(args) != arity(idx):
+                raise _lib.Mi355Error('%s takes %d arguments before the stream, the step has %d' % (name, arity(idx), len(args)))
+            st.fn, st.nargs = idx, len(args)
+            if name in self.SIDE_STEPS:
+                st.where = PLAN_SIDE_RR if self.n_side > 1 else PLAN_SIDE
+            elif id(args) in self._side_ids:
+                st.where = PLAN_SIDE
+            for j, a in enumerate(args):
+                st.arg[j] = _slot(a)
+        ent = (arr, n, [i for i in range(n) if arr[i].host], steps)
+        cache[key] = ent
+        return ent
+
+    def _run(self, steps, stream, begin=0, end=None):
+        """Enqueue `steps[begin:end]`: main-stream launches on `stream`; with the side stream enabled
+        (MI355_SIDE_STREAM=1) the weight-gradient launches (and the box head) go to a second HIP stream, forked behind
+        everything issued so far: a wgrad and the data gradient of the same layer only share inputs, so they run
+        concurrently and fill each other's ramp-up / tail; `join_side()` is the fence in front of the consumers of dW."""
+        arr, n, hosts, _ = self._compiled(steps)
+        end = n if end is None else end
+        side = side2 = None
+        if self._side_active():
+            side = self._side_stream().cuda_stream
+            if self.n_side > 1:
+                if self._side2 is None:
+                    self._side2 = torch.cuda.Stream(device=self.dev)
+                side2 = self._side2.cuda_stream
+        run, state = self.lib.mi355_plan_run, self._pstate
+        s, ss, ss2, pstate = c_vp(stream), c_vp(side), c_vp(side2), ctypes.byref(state)
+        pos = begin
+        while True:
+            rc = run(arr, c_int(pos), c_int(end), s, ss, ss2, pstate)
+            if rc == 0:
+                return
+            if rc == 1:                                        # stopped in front of a host step
+                steps[state.next][0](stream)
+                pos = state.next + 1
+                continue
+            name = steps[state.failed][2] if 0 <= state.failed < n else '?'
+            raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, self.lib.mi355_last_error().decode()))
+
+    @property
+    def _side_dirty(self):
+        return bool(self._pstate.side_dirty or self._pstate.side2_dirty)
+
+    def _side_active(self):
+        """Two-stream replay?  Not while a hipGraph is being captured unless MI355_GRAPH_BRANCH=1 (a branched graph
+        replays no faster than the single-stream order: the step is GPU-bound)."""
+        if not self.use_side:
+            return False
+        if torch.cuda.is_current_stream_capturing():
+            return os.environ.get('MI355_GRAPH_BRANCH', '0') == '1'
+        return True
 
     def _side_stream(self):
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(device=self.dev)
         return self._side
 
+    def _join(self, fold_only):
+        if self._side is None:
+            return
+        rc = self.lib.mi355_plan_join(c_vp(self._stream()), c_vp(self._side.cuda_stream),
+                                      c_vp(self._side2.cuda_stream if self._side2 is not None else None),
+                                      ctypes.byref(self._pstate), c_int(fold_only))
+        if rc:
+            raise _lib.Mi355Error('plan_join: %s' % self.lib.mi355_last_error().decode())
+
     def _fold_side2(self):
         """Order the primary side stream behind the second one (before anything that needs ALL weight gradients)."""
-        if getattr(self, '_side2_dirty', False):
-            self._side_stream().wait_stream(self._side2)
-            self._side2_dirty = False
-            self._side_dirty = True
+        self._join(1)
 
     def join_side(self):
-        self._fold_side2()
-        if getattr(self, '_side_dirty', False):
-            torch.cuda.current_stream(self.dev).wait_stream(self._side)
-            self._side_dirty = False
+        """The current stream waits for everything issued to the side stream(s)."""
+        self._join(0)
 
     # ------------------------------------------------------------------ layers / parameters
     def _collect_layers(self):
@@ -1059,34 +1159,54 @@ class RetinaPlan(object):
                         all(v == 1 for v in seen.values()) and os.environ.get('MI355_PG_OVERWRITE', '1') == '1')
         return self._ow
 
-    def _zero_gaps(self, arena):
+    def _gap_views(self, arena):
         """Overwrite mode: the arena ranges NO table descriptor stores (frozen / unused parameters, alignment, the
-        space-to-depth stem's weight whose gradient is added by the unpack launch), merged; zeroed per backward."""
-        cache = self.__dict__.setdefault('_gap_cache', {})
-        if arena not in cache:
-            self._carve_grads(arena)
-            base, cov = self.grad_arenas[arena].data_ptr(), []
-            for s in self.pgrad_specs:
-                d = self._layer_desc(s, arena)
-                if d.dW == self._stem_dwp_ptr():       # (this descriptor keeps adding: all of its targets are gaps)
-                    continue
-                if d.dW:
-                    cov.append(((d.dW - base) // 4, s.conv.weight.numel()))
-                for q in (d.dgamma, d.dbeta, d.dconv_bias):
-                    if q:
-                        cov.append(((q - base) // 4, s.K))
-            cov.sort()
-            gaps, pos = [], 0
-            for lo, n in cov:
-                assert 0 <= lo and lo + n <= self.grad_numel and lo >= pos, 'overlapping gradient targets'
-                if lo > pos:
-                    gaps.append((pos, lo))
-                pos = lo + n
-            if pos < self.grad_arenas[arena].numel():
-                gaps.append((pos, self.grad_arenas[arena].numel()))
-            cache[arena] = [self.grad_arenas[arena][lo:hi] for lo, hi in gaps]
-        for view in cache[arena]:
-            view.zero_()
+        space-to-depth stem's weight whose gradient is added by the unpack launch), merged."""
+        self._carve_grads(arena)
+        base, cov = self.grad_arenas[arena].data_ptr(), []
+        for s in self.pgrad_specs:
+            d = self._layer_desc(s, arena)
+            if d.dW == self._stem_dwp_ptr():       # (this descriptor keeps adding: all of its targets are gaps)
+                continue
+            if d.dW:
+                cov.append(((d.dW - base) // 4, s.conv.weight.numel()))
+            for q in (d.dgamma, d.dbeta, d.dconv_bias):
+                if q:
+                    cov.append(((q - base) // 4, s.K))
+        cov.sort()
+        gaps, pos = [], 0
+        for lo, n in cov:
+            assert 0 <= lo and lo + n <= self.grad_numel and lo >= pos, 'overlapping gradient targets'
+            if lo > pos:
+                gaps.append((pos, lo))
+            pos = lo + n
+        if pos < self.grad_arenas[arena].numel():
+            gaps.append((pos, self.grad_arenas[arena].numel()))
+        return [self.grad_arenas[arena][lo:hi] for lo, hi in gaps]
+
+    def _zero_tensors(self, arena):
+        """Everything a backward pass accumulates into, zeroed by ONE launch in front of it (mi355_zero_ranges)."""
+        ts = self._gap_views(arena) if self._overwrite_grads() else [self.grad_arenas[arena]]
+        if self.scratch.numel() > 1:                   # (atomic mode's raw gradients; the slab mode has none)
+            ts.append(self.scratch)
+        if getattr(self, 'stem_s2d', False):
+            ts.append(self.stem_dwp)
+        return ts + self._zero_extra()
+
+    def _zero_for_backward(self, arena, stream):
+        cache = self.__dict__.setdefault('_zero_tables', {})
+        ent = cache.get(arena)
+        if ent is None:
+            ts = [t for t in self._zero_tensors(arena) if t.numel()]
+            rows = []
+            for t in ts:
+                assert t.is_contiguous() and (t.numel() * t.element_size()) % 4 == 0 and t.data_ptr() % 4 == 0
+                rows += [t.data_ptr(), t.numel() * t.element_size()]
+            tab = torch.tensor(rows, dtype=torch.int64).to(self.dev) if rows else None
+            big = max([t.numel() * t.element_size() for t in ts] + [0])
+            ent = cache[arena] = (tab, len(ts), ts, max(1, min(1024, big >> 16)))
+        if ent[1]:
+            _lib.call('mi355_zero_ranges', ptr(ent[0]), c_int(ent[1]), c_int(ent[3]), c_vp(stream))
 
     def begin_backward(self, g_cls, g_reg):
         """Zero the gradient arena, loss backward (d loss / d head outputs).  Returns the arena index."""
@@ -1100,15 +1220,7 @@ class RetinaPlan(object):
         else:
             gl[0:1].copy_(g_cls.reshape(1) if g_cls is not None else torch.zeros(1, device=self.dev))
             gl[1:2].copy_(g_reg.reshape(1) if g_reg is not None else torch.zeros(1, device=self.dev))
-        if self._overwrite_grads():
-            self._zero_gaps(arena)
-        else:
-            self.grad_arenas[arena].zero_()
-        if self.scratch.numel() > 1:                   # (atomic mode's raw gradients; the slab mode has none)
-            self.scratch.zero_()
-        if getattr(self, 'stem_s2d', False):
-            self.stem_dwp.zero_()
-        self._zero_extra()
+        self._zero_for_backward(arena, st)
         annot = self._annot
         _lib.call('mi355_focal_loss_bwd', ptr(self.cls), ptr(self.reg), ptr(self._anchors), ptr(annot),
                   ptr(self.argmax), ptr(self.state), ptr(self.num_pos), ptr(gl),
@@ -1118,9 +1230,6 @@ class RetinaPlan(object):
         self._bwd_pos = 0
         return arena
 
-    def _side_active(self):
-        return self.use_side and not torch.cuda.is_current_stream_capturing()
-
     def run_backward_segment(self, seg):
         """Backward launches up to seg[0], then the parameter gradients of arena range [seg[1], seg[2]).
         With the side stream the table launch queues there behind this range's wgrads (stream order), i.e.
@@ -1129,7 +1238,7 @@ class RetinaPlan(object):
         st = self._stream()
         arena = self.last_arena
         steps = self.bwd_steps if arena == 0 else self.bwd_steps_alt
-        self._run(steps[self._bwd_pos:seg[0]], st)
+        self._run(steps, st, self._bwd_pos, seg[0])
         self._bwd_pos = seg[0]
         self._fold_side2()
         if self._side_active() and self._side_dirty:
@@ -1174,7 +1283,8 @@ class RetinaPlan(object):
         return [tuple(r) for r in out]
 
     def _zero_extra(self):
-        pass
+        """More tensors the backward accumulates into (subclasses)."""
+        return []
 
     def _extra_param_grads(self, arena, stream):
         pass

@@ -744,29 +744,6 @@ class EffDetPlan(RetinaPlan):
     SIDE_STEPS = RetinaPlan.SIDE_STEPS + ('mi355_dwconv_wgrad', 'mi355_dwconv_wgrad_f32', 'mi355_dwconv_wgrad_slabs',
                                           'mi355_dwconv_wgrad_slabs_multi')
 
-    def _run(self, steps, stream):
-        """As RetinaPlan._run (weight gradients on the side stream: they only read activations / output
-        gradients that are final by then and write their own G buffers), plus the python-side pseudo steps."""
-        s = c_vp(stream)
-        lib = self.lib
-        arena = self.last_arena
-        side = self._side_stream() if (self.use_side and not torch.cuda.is_current_stream_capturing()) else None
-        fork = lib.mi355_stream_fork
-        for fn, args, name in steps:
-            if side is not None and fn is not None and (name in self.SIDE_STEPS or id(args) in self._side_ids):
-                ss = c_vp(side.cuda_stream)
-                rc = fork(s, ss) or fn(*args, ss)
-                self._side_dirty = True
-                if rc:
-                    raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, lib.mi355_last_error().decode()))
-                continue
-            if fn is None:
-                raise _lib.Mi355Error('unknown deferred step %r' % (name,))
-            else:
-                rc = fn(*args, s)
-            if rc:
-                raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, lib.mi355_last_error().decode()))
-
     def grad_view(self, p, arena):
         off = self.grad_offsets[id(p)]
         flat = self.grad_arenas[arena][off:off + p.numel()]
@@ -775,9 +752,7 @@ class EffDetPlan(RetinaPlan):
         return flat.view(p.shape)
 
     def _zero_extra(self):
-        if getattr(self, '_dw_atomic', False):
-            self.dw_scratch.zero_()
-        self._zb.zero_()
+        return ([self.dw_scratch] if getattr(self, '_dw_atomic', False) else []) + [self._zb]
 
     def _extra_param_grads(self, arena, stream):
         """Depthwise layers: dW = G * scale, frozen-BN gamma / beta gradients — one table-driven launch for all of

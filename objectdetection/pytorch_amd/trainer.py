@@ -243,6 +243,15 @@ class Trainer(object):
             self._graphs = (g1, g2)
             return first                           # this step already ran eagerly (the warm-up)
         g1, g2 = self._graphs
+        if self._skip_sig != (id(self._g_plan), tuple(p.requires_grad for p in self.params)):
+            # a requires_grad flag flipped: the skip table (pointer + count are by-value arguments of the captured
+            # launches) changed: capture the update again
+            g2 = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(dev)
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._update(self._g_plan, self._s_flag)
+            self._graphs = (g1, g2)
+        self._refresh_hyper()
         draw = getattr(self._g_plan, 'draw_drop_connect', None)
         if draw is not None:
             draw()                                 # stochastic-depth uniforms are drawn outside the captured region
@@ -263,10 +272,35 @@ class Trainer(object):
             self._skip_sig = sig
         return self._skip
 
+    def _hyper_values(self):
+        return (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.wd))
+
+    def _refresh_hyper(self):
+        """Graph mode: lr / betas / eps / weight_decay live in a device vector the captured AdamW launch reads, so
+        that `ReduceLROnPlateau(trainer.optimizer)` (train.py:268, :346) and any other scheduler edit keep driving
+        the replays; refreshed (one 20-byte copy on the launch stream) only when a value changed."""
+        vals = self._hyper_values()
+        if getattr(self, '_hyper_sig', None) != vals:
+            if getattr(self, '_hyper', None) is None:
+                self._hyper = torch.zeros(8, dtype=torch.float32, device=self.flat.device)
+            self._hyper[:5].copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=False)
+            self._hyper_sig = vals
+        return self._hyper
+
     def _update(self, plan, loss_flag):
         grad = plan.grad_arenas[plan.last_arena]
         s = c_vp(torch.cuda.current_stream(grad.device).cuda_stream)
         skip, nskip = self._skip_table(plan)
+        if self.use_graph:
+            capturing = torch.cuda.is_current_stream_capturing()
+            hyper = self._hyper if capturing else self._refresh_hyper()       # (no copy inside a capture)
+            self._call('mi355_grad_sumsq_masked', ptr(grad), c_i64(plan.grad_numel_padded), ptr(self.partials),
+                       ptr(skip), c_int(nskip), s)
+            self._call('mi355_adamw_prepare', ptr(self.partials), ptr(loss_flag), c_f32(self.clip_norm),
+                       ptr(self.state), s)
+            self._call('mi355_adamw_flat_hyper', ptr(self.flat), ptr(grad), ptr(self.m), ptr(self.v),
+                       c_i64(self.npad), ptr(hyper), ptr(self.state), c_int(1), ptr(skip), c_int(nskip), s)
+            return
         self._call('mi355_grad_sumsq_masked', ptr(grad), c_i64(plan.grad_numel_padded), ptr(self.partials),
                    ptr(skip), c_int(nskip), s)
         self._call('mi355_adamw_prepare', ptr(self.partials), ptr(loss_flag), c_f32(self.clip_norm),

@@ -344,3 +344,61 @@ def test_reduce_lr_on_plateau_drives_the_flat_optimizer():
     sd = tr.optimizer.state_dict()
     assert sd['param_groups'][0]['lr'] == tr.lr and sd['flat_state']['exp_avg'].shape == tr.m.shape
     tr.optimizer.load_state_dict(sd)
+
+
+def test_graph_mode_follows_the_lr_scheduler_and_requires_grad_flips():
+    """Trainer(graph=True): the captured AdamW launch reads lr / betas / eps / weight_decay from a device vector
+    that is refreshed in front of a replay, so `ReduceLROnPlateau` (train.py:268, :346) keeps driving the update, and
+    a requires_grad flip (train.py:206-216) re-captures the update graph with the new skip table: the graph-mode
+    trainer must follow an eager trainer of the same model bit for bit through both events."""
+    from objectdetection.pytorch_amd.trainer import Trainer
+    dev = torch.device('cuda', 0)
+    img = torch.from_numpy(synth.synth_images(2, 64, 64, seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(2, 64, 64, 4, 8, 8, seed=2)).to(dev)
+    flats = []
+    for graph in (False, True):
+        model = _model(dev)
+        tr = Trainer(model, lr=1e-3, graph=graph, max_annots=ann.shape[1])
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(tr.optimizer, patience=0, factor=0.1)
+        tr.step(img, ann)                       # (graph mode: eager warm-up + capture)
+        tr.step(img, ann)                       # first replay at lr 1e-3
+        sched.step(1.0)
+        sched.step(2.0)                         # no improvement -> lr * 0.1
+        assert abs(tr.lr - 1e-4) < 1e-12
+        tr.step(img, ann)                       # replay must use 1e-4
+        a = tr.flat.clone()
+        tr.step(img, ann)
+        d_small = float((tr.flat - a).abs().max())
+        frozen = model.regressionModel.output.weight
+        frozen.requires_grad_(False)
+        b = frozen.detach().clone()
+        tr.step(img, ann)
+        assert torch.equal(frozen.detach(), b), 'a frozen parameter moved (skip table frozen at capture?)'
+        torch.cuda.synchronize()
+        flats.append((tr.flat.clone(), d_small))
+    assert flats[1][1] < 2.5e-4                 # |dp| <= lr-ish per Adam step: 1e-3 would give ~1e-3
+    assert torch.equal(flats[0][0], flats[1][0]), 'graph-mode parameters differ from the eager trainer'
+
+
+@pytest.mark.parametrize('branch', ['0', '1'])
+def test_graph_replay_is_bit_identical_to_eager(monkeypatch, branch):
+    """hipGraph replay == the eager two-stream schedule, bit for bit (losses and every parameter after 4 steps on 4
+    different batches).  branch=1 captures the BRANCHED graph (weight gradients + box head on the side stream): the
+    fork / join edges come from the step table (csrc/plan_run.hip), not from host-side flags, so the capture holds the
+    same dependency edges as the eager replay."""
+    from objectdetection.pytorch_amd.trainer import Trainer
+    monkeypatch.setenv('MI355_GRAPH_BRANCH', branch)
+    dev = torch.device('cuda', 0)
+    B, H, W, nc = 2, 128, 128, 8
+    batches = [(torch.from_numpy(synth.synth_images(B, H, W, seed=10 + i)).to(dev),
+                torch.from_numpy(synth.synth_annotations(B, H, W, 6, 8 + 2 * (i % 2), nc, seed=20 + i)).to(dev))
+               for i in range(4)]
+    out = {}
+    for mode in (False, True):
+        tr = Trainer(_model(dev, depth=50), graph=mode, max_annots=16)
+        losses = torch.stack([tr.step(im, an).clone() for im, an in batches])
+        torch.cuda.synchronize()
+        out[mode] = (losses.cpu(), tr.flat.clone().cpu())
+    assert torch.equal(out[True][0], out[False][0]), 'losses differ'
+    diff = (out[True][1] != out[False][1]).sum().item()
+    assert diff == 0, '%d of %d parameters differ between graph replay and eager' % (diff, out[True][1].numel())
