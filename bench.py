@@ -22,7 +22,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, 'tests')):
+for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tools')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -39,6 +39,7 @@ import torch.distributed as dist   # noqa: E402
 import synth                # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparse figure)
+PEAK_F32_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 (exact f32) = the fp32 vector rate
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s is what a float4 copy reaches)
 
 
@@ -61,12 +62,19 @@ def parse():
     ap.add_argument('--infer', action='store_true',
                     help='measure inference instead (SURVEY 8d): heads at --batch, and the B=1 decode + NMS path; '
                          'prints its own JSON line (not the headline metric)')
+    ap.add_argument('--precision', default='bf16', choices=('bf16', 'fp32'),
+                    help="'fp32': the plan's fp32-accurate mode (the mode held to the north-star 1e-4; roofline against the "
+                         "157.3 TFLOP/s f32 matrix peak)")
+    ap.add_argument('--sync-bn', action='store_true',
+                    help='BASELINE configs[2] as named: utils.utils.replace_w_sync_bn + BatchNorm in train mode (batch '
+                         'statistics, cross-replica all-reduce of [sum | sum^2] per layer and direction); on one GPU the '
+                         'collectives run on a world-size-1 RCCL group')
     ap.add_argument('--torch-optim', action='store_true',
                     help='autograd + torch clip/AdamW instead of the flat HIP optimizer')
     return ap.parse_args()
 
 
-def build_model(depth, num_classes, dev, arch='retinanet'):
+def build_model(depth, num_classes, dev, arch='retinanet', precision='bf16', sync_bn=False):
     if arch not in ('retinanet', 'ksevendet', 'ksevendet-panet') and not arch.startswith('efficientdet-d'):
         raise SystemExit("--arch must be 'retinanet', 'ksevendet[-panet]' or 'efficientdet-dN', got %r" % arch)
     if arch.startswith('ksevendet'):
@@ -97,7 +105,16 @@ def build_model(depth, num_classes, dev, arch='retinanet'):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.to(dev)
     model.train()
-    model.freeze_bn()                       # train.py:273-277
+    if sync_bn:
+        # configs[2] "DP + SyncBN": utils/utils.py:140-168 swaps the BatchNorm2d layers, which then stay in train mode
+        # (batch statistics, running-stat updates); no freeze_bn
+        from objectdetection.pytorch_amd.utils.utils import replace_w_sync_bn
+        replace_w_sync_bn(model)
+        model.train()
+    else:
+        model.freeze_bn()                   # train.py:273-277
+    if precision == 'fp32':
+        model.precision = 'fp32'
     return model, sd
 
 
@@ -132,7 +149,7 @@ def conv_flops(plan):
 
 
 CONV_STEPS = ('mi355_conv_gather', 'mi355_conv_gather_splitk', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_slabs',
-              'mi355_conv_wgrad_multi')
+              'mi355_conv_wgrad_multi', 'mi355_conv_gather_f32', 'mi355_conv_wgrad_slabs_f32')
 
 
 def conv_bytes(plan):
@@ -140,39 +157,27 @@ def conv_bytes(plan):
     read once, every result written once (bf16 activations, bf16 weight shadows, fp32 dW slabs)."""
     total = 0.0
     for fn, args, name in plan.fwd_steps + plan.bwd_steps:
-        if name not in CONV_STEPS:
-            continue
-        L = args[0]._obj
-        gather = name.startswith('mi355_conv_gather')
-        # weights / one dW tile set (fp32 = 2 x 2 B); a multi-layer wgrad launch writes one per problem (= per layer)
-        total += 2.0 * L.K * L.T * L.prob[0].C * (1 if gather else 2) * (L.nprob if name.endswith('_multi') else 1)
-        for i in range(L.nprob):
-            p = L.prob[i]
-            M = p.N * p.P * p.Q
-            total += 2.0 * p.N * p.H * p.W * p.C
-            if gather:
-                total += M * L.K * (4.0 if L.out_f32 else 2.0)
-                total += (2.0 * M * L.K / (4 ** p.add_shift)) if p.addend else 0.0
-                total += 2.0 * M * L.K if p.mask else 0.0
-            else:
-                total += 2.0 * M * L.K
+        if name in CONV_STEPS:
+            total += conv_launch_bytes(args[0]._obj, name, plan.esz)
     return total
 
 
-def conv_launch_bytes(L, name):
-    """One conv launch of `conv_bytes`: every operand read once, every result written once."""
+def conv_launch_bytes(L, name, esz=2):
+    """One conv launch of `conv_bytes`: every operand read once, every result written once (`esz` = bytes per stored
+    activation / gradient / weight-shadow element: 2 in the bf16 mode, 4 in the fp32-accurate mode)."""
     gather = name.startswith('mi355_conv_gather')
-    total = 2.0 * L.K * L.T * L.prob[0].C * (1 if gather else 2) * (L.nprob if name.endswith('_multi') else 1)
+    # weight shadows / one fp32 dW tile set; a multi-layer wgrad launch writes one per problem (= per layer)
+    total = float(L.K * L.T * L.prob[0].C) * (esz if gather else 4) * (L.nprob if name.endswith('_multi') else 1)
     for i in range(L.nprob):
         p = L.prob[i]
         M = p.N * p.P * p.Q
-        total += 2.0 * p.N * p.H * p.W * p.C
+        total += float(esz) * p.N * p.H * p.W * p.C
         if gather:
-            total += M * L.K * (4.0 if L.out_f32 else 2.0)
-            total += (2.0 * M * L.K / (4 ** p.add_shift)) if p.addend else 0.0
-            total += 2.0 * M * L.K if p.mask else 0.0
+            total += M * L.K * (4.0 if L.out_f32 else float(esz))
+            total += (float(esz) * M * L.K / (4 ** p.add_shift)) if p.addend else 0.0
+            total += float(esz) * M * L.K if p.mask else 0.0
         else:
-            total += 2.0 * M * L.K
+            total += float(esz) * M * L.K
     return total
 
 
@@ -192,7 +197,7 @@ def plan_launch_bytes(plan):
         for fn, args, name in steps:
             b = 0.0
             if name in CONV_STEPS:
-                b = conv_launch_bytes(args[0]._obj, name)
+                b = conv_launch_bytes(args[0]._obj, name, plan.esz)
             else:
                 seen = set()
                 for a in args:
@@ -211,25 +216,43 @@ def plan_launch_bytes(plan):
     return total, per_kernel
 
 
+from csrc_hash import csrc_hash   # noqa: E402  (tools/csrc_hash.py)
+
+
+def traffic_tag(args):
+    return '%s%s_%d_b%d_%s%s' % (args.arch.replace('-', '_'), ('_r%d' % args.depth) if not args.arch.startswith('efficientdet') else '',
+                               args.size, args.batch, args.precision, '_syncbn' if args.sync_bn else '')
+
+
 def measured_traffic(args):
-    """HBM-side bytes per step of the conv kernels from the COMMITTED PMC passes (tools/collect_traffic.py;
-    FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950): a kept profile of the same
-    command, not a measurement of this run (`traffic_source: "committed"`); only for the workload the passes
-    were taken on."""
-    if not (args.arch == 'retinanet' and args.depth == 50 and args.size == 512 and args.batch == 16):
-        return None, None
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
-        path = os.path.join(ROOT, 'profiles', name)
+    """HBM-side bytes per step from the COMMITTED PMC passes of this very workload (tools/collect_traffic.py;
+    FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950): a kept profile of the same command, not
+    a measurement of this run (`traffic_source: "committed"`).  The file records the hash of the kernel sources it
+    was collected on; `stale` tells whether they have changed since.  -> (dict | None)"""
+    tag = traffic_tag(args)
+    for rnd in ('r03', 'r02', 'r01'):
+        path = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (rnd, tag))
+        if not os.path.exists(path) and tag == 'retinanet_r50_512_b16_bf16':
+            path = os.path.join(ROOT, 'profiles', '%s_pmc_traffic.json' % rnd)      # (rounds 1-2: the headline only)
         if os.path.exists(path):
             t = json.load(open(path))
-            return t['conv_kernels_bytes_per_step'], 'profiles/' + name
-    return None, None
+            return {'file': 'profiles/' + os.path.basename(path), 'conv': t.get('conv_kernels_bytes_per_step'),
+                    'step': t.get('all_kernels_bytes_per_step'), 'csrc_sha16': t.get('csrc_sha16'),
+                    'stale': t.get('csrc_sha16') != csrc_hash()}
+    return None
 
 
-def time_conv_kernels(plan, iters):
+def time_conv_kernels(plan, iters, names=None, prefix=None):
     """HIP-event time of ONLY the MFMA conv launches of one step (forward gather convs,
-    backward gather convs = dgrad, wgrad), replayed back-to-back on the launch stream."""
-    steps = [s for s in plan.fwd_steps + plan.bwd_steps if s[2] in CONV_STEPS]
+    backward gather convs = dgrad, wgrad), replayed back-to-back on the launch stream.  `prefix`: the launches whose
+    entry point starts with it instead (the BatchNorm passes of the train-mode / synchronised-BN plan, their
+    all-reduce host steps included)."""
+    if prefix is not None:
+        steps = [s for s in plan.fwd_steps + plan.bwd_steps if s[2].startswith(prefix)]
+    else:
+        steps = [s for s in plan.fwd_steps + plan.bwd_steps if s[2] in (names or CONV_STEPS)]
+    if not steps:
+        return 0.0, 0
     st = torch.cuda.current_stream()
     plan.grad_arenas[0].zero_()
     plan._run(steps, st.cuda_stream)
@@ -354,8 +377,19 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
+    if world == 1 and args.sync_bn:
+        # the SyncBN collectives need a process group: a world-size-1 RCCL group exercises the real RCCL stream
+        # machinery on one GPU (the all-reduce of one rank is a device-side no-op copy, its launch cost is real)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(port))
+        os.environ.setdefault('MI355_BN_FORCE_ALLREDUCE', '1')
+        dist.init_process_group(os.environ.get('MI355_DIST_BACKEND', 'nccl'), rank=0, world_size=1, device_id=dev)
     num_classes = 80
-    model, sd = build_model(args.depth, num_classes, dev, args.arch)
+    model, sd = build_model(args.depth, num_classes, dev, args.arch, args.precision, args.sync_bn)
     name = ('RetinaNet-R%d' % args.depth if args.arch == 'retinanet' else
             'KSevenDet-R%d-%s' % (args.depth, 'PANetFPN' if args.arch.endswith('panet') else 'FPN') if args.arch.startswith('ksevendet')
             else 'EfficientDet-D' + args.arch[-1])
@@ -405,13 +439,23 @@ def main():
     for i in range(args.steps):
         step()
         marks[i + 1].record()
-    host_ms = 1e3 * (time.perf_counter() - t0) / args.steps       # host time to ENQUEUE a step (no sync inside the loop)
+    loop_host_ms = 1e3 * (time.perf_counter() - t0) / args.steps  # host time per step INSIDE the loop: includes the waits on a
+    #                                                               full launch queue (the GPU is the bottleneck), not a host cost
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     own_ms = 1e3 * elapsed / args.steps
+    final_loss = [round(float(v), 5) for v in (loss_acc / (args.warmup + args.steps)).tolist()]
+    # host cost of a step proper: ONE step enqueued onto an idle stream (nothing to wait for), best of 5
+    host_ms = 1e9
+    for _ in range(5):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step()
+        host_ms = min(host_ms, 1e3 * (time.perf_counter() - th))
+    torch.cuda.synchronize()
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     ranks_seen, per_rank_ms = 1, [round(own_ms, 3)]
@@ -431,16 +475,18 @@ def main():
         'metric': 'images/sec training (%s, %dx%d, bs=%d/GPU)' % (name, S, S, B),
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'ms_per_step_median': round(median_ms, 3),
-        'host_enqueue_ms_per_step': round(host_ms, 3),
+        'host_enqueue_ms_per_step': round(host_ms, 3), 'host_loop_ms_per_step': round(loop_host_ms, 3),
         'ranks_seen': ranks_seen, 'ms_per_step_per_rank': per_rank_ms, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': '%s, %dx%d, bf16 MFMA convs (fp32 accumulate, fp32 loss '
-                               'and optimizer), batch=%d/GPU, fwd+FocalLoss+bwd+clip+AdamW, frozen BN'
-                               % (name, S, S, B),
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s, %dx%d, %s, batch=%d/GPU, fwd+FocalLoss+bwd+clip+AdamW, %s'
+                               % (name, S, S, 'bf16 MFMA convs (fp32 accumulate, fp32 loss and optimizer)' if args.precision == 'bf16'
+                                  else 'fp32-accurate mode: exact-f32 MFMA convs (v_mfma_f32_16x16x4_f32), fp32 everywhere', B,
+                                  'SynchronizedBatchNorm2d in train mode (batch statistics + [sum | sum^2] all-reduce per layer and direction)'
+                                  if args.sync_bn else 'frozen BN'),
                    'global_batch': world * B, 'parallelism': 'dp%d' % world,
                    'dp_exchange': ('per-range all-reduce overlapped with backward' if os.environ.get('MI355_DP_OVERLAP', '1') != '0' else 'one all-reduce after backward') if world > 1 else None,
                    'launch': 'hipGraph replay' if (args.graph and not args.torch_optim and not (world > 1 and os.environ.get('MI355_DP_OVERLAP', '1') != '0')) else 'eager',
-                   'final_loss': [round(float(v), 5) for v in (loss_acc / (args.warmup + args.steps)).tolist()]},
+                   'final_loss': final_loss},
     }
     plan = model._plans[next(iter(model._plans))]
     conv_bound = args.arch == 'retinanet' or args.arch.startswith('ksevendet')
@@ -450,8 +496,14 @@ def main():
         nbytes, per_kernel = plan_launch_bytes(plan)
         top = sorted(per_kernel.items(), key=lambda kv: -kv[1])[:4]
         gbs = nbytes / (median_ms * 1e-3) / 1e9
+        tr = measured_traffic(args)
         out['roofline'] = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                           'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'traffic_source': None,
+                           'frac': round(gbs / PEAK_HBM_GBS, 4), 'traffic': tr['step'] if tr else None,
+                           'traffic_source': 'committed' if tr else None,
+                           'traffic_note': ('HBM-side bytes of ALL kernels of one step (PMC passes of the same command, kept in %s, '
+                                            'collected on kernel sources %s; %s)' % (tr['file'], tr['csrc_sha16'],
+                                            'sources CHANGED since' if tr['stale'] else 'sources unchanged since')) if tr else None,
+                           'traffic_stale': tr['stale'] if tr else None,
                            'algorithmic_bytes_per_step': round(nbytes),
                            'kernel': 'whole step (%d launches): every launch\'s operands once; largest by bytes: %s'
                                      % (len(plan.prep_steps) + len(plan.fwd_steps) + len(plan.bwd_steps),
@@ -461,16 +513,27 @@ def main():
         fwd_f, train_f = conv_flops(plan)
         conv_ms, nlaunch = time_conv_kernels(plan, 5)
         ach = train_f / (conv_ms * 1e-3) / 1e12
-        traffic, src = measured_traffic(args)
-        out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-                           'traffic_source': 'committed' if src else None,
-                           'traffic_note': 'HBM-side bytes of the conv kernels per step (PMC passes of the same command, kept in %s; not measured in this run)' % src if src else None,
+        tr = measured_traffic(args)
+        peak = PEAK_BF16_TFLOPS if args.precision == 'bf16' else PEAK_F32_TFLOPS
+        out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak,
+                           'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': tr['conv'] if tr else None,
+                           'traffic_source': 'committed' if tr else None,
+                           'traffic_note': ('HBM-side bytes of the conv kernels per step (PMC passes of the same command, kept in %s, '
+                                            'collected on kernel sources %s; %s; not measured in this run)' % (tr['file'], tr['csrc_sha16'],
+                                            'sources CHANGED since' if tr['stale'] else 'sources unchanged since')) if tr else None,
+                           'traffic_stale': tr['stale'] if tr else None,
                            'algorithmic_bytes_per_step': round(conv_bytes(plan)),
                            'kernel': 'conv_gather(+row3, split-K) + conv_wgrad kernels (%d launches/step)' % nlaunch,
                            'algorithmic_gflop_per_image': round(train_f / B / 1e9, 2),
                            'conv_ms_per_step': round(conv_ms, 3)}
-    if args.arch.startswith('ksevendet'):          # (supplementary line of SURVEY 8 f-3: training step + roofline only)
+        if args.sync_bn:
+            bn_ms, nbn = time_conv_kernels(plan, 5, prefix=('mi355_bn_nhwc', 'py:bn_allreduce'))
+            nlayers = len(plan.bn_saved)
+            out['sync_bn'] = {'bn_layers': nlayers, 'bn_launches_per_step': nbn, 'bn_ms_per_step': round(bn_ms, 3),
+                              'bn_us_per_layer_and_direction': round(1e3 * bn_ms / max(2 * nlayers, 1), 2),
+                              'collectives_per_step': sum(1 for st in plan.fwd_steps + plan.bwd_steps if st[2].startswith('py:')),
+                              'group': '%s, world size %d' % (dist.get_backend() if dist.is_initialized() else None, world)}
+    if args.arch.startswith('ksevendet') or args.sync_bn:   # (supplementary lines: training step + roofline only)
         args.no_infer = args.no_cpu_baseline = True
     if rank == 0 and world == 1 and not args.no_infer:
         inf = infer_bench(args, model, name, img, dev, emit=False)         # also inference img/s
@@ -479,7 +542,7 @@ def main():
         out['cpu_baseline'] = cpu_baseline(args.depth, S, sd, num_classes, args.arch)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

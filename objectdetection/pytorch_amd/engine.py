@@ -116,6 +116,11 @@ class LayerSpec(object):
         return self.pad, self.pad, P, Q
 
 
+def group_exchange(world):
+    """Issue the BatchNorm statistics all-reduce?  (more than one replica, or the world-size-1 pricing run)"""
+    return world > 1 or os.environ.get('MI355_BN_FORCE_ALLREDUCE') == '1'
+
+
 def precision_of(model):
     """'bf16' (throughput mode: bf16 MFMA operands, fp32 accumulate) or 'fp32' (the reference's own precision,
     train.py:259-321 runs without autocast: fp32 activations / gradients / shadows on v_mfma_f32_16x16x4_f32).
@@ -276,6 +281,8 @@ class RetinaPlan(object):
         (MI355_SIDE_STREAM=1) the weight-gradient launches (and the box head) go to a second HIP stream, forked behind
         everything issued so far: a wgrad and the data gradient of the same layer only share inputs, so they run
         concurrently and fill each other's ramp-up / tail; `join_side()` is the fence in front of the consumers of dW."""
+        if os.environ.get('MI355_PLAN_PY') == '1':
+            return self._run_py(steps, stream, begin, end)
         arr, n, hosts, _ = self._compiled(steps)
         end = n if end is None else end
         side = side2 = None
@@ -298,6 +305,24 @@ class RetinaPlan(object):
                 continue
             name = steps[state.failed][2] if 0 <= state.failed < n else '?'
             raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, self.lib.mi355_last_error().decode()))
+
+    def _run_py(self, steps, stream, begin=0, end=None):
+        """MI355_PLAN_PY=1: the same replay as a Python loop (one ctypes call per launch and per fork edge): the form
+        mi355_plan_run replaced, kept for A/B timing of the host cost (tools/host_cost.py)."""
+        s = c_vp(stream)
+        side = c_vp(self._side_stream().cuda_stream) if self._side_active() else None
+        fork = self.lib.mi355_stream_fork
+        for fn, args, name in steps[begin:end]:
+            if name.startswith('py:'):
+                fn(stream)
+                continue
+            if side is not None and (name in self.SIDE_STEPS or id(args) in self._side_ids):
+                rc = fork(s, side) or fn(*args, side)
+                self._pstate.side_dirty = 1
+            else:
+                rc = fn(*args, s)
+            if rc:
+                raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, self.lib.mi355_last_error().decode()))
 
     @property
     def _side_dirty(self):
@@ -669,7 +694,9 @@ class RetinaPlan(object):
         from .utils.sync_batchnorm.batchnorm import SynchronizedBatchNorm2d
         if isinstance(bn, SynchronizedBatchNorm2d) and dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(bn.group)
-            if world > 1:
+            # (MI355_BN_FORCE_ALLREDUCE=1: exchange on a world-size-1 group too, to price the collectives of
+            #  BASELINE configs[2] against the real RCCL stream machinery on one GPU: bench.py --sync-bn)
+            if world > 1 or os.environ.get('MI355_BN_FORCE_ALLREDUCE') == '1':
                 return True, bn.group, world
         # (tests: `bn.force_sync_formula` puts ONE replica on the synchronised normaliser, so that a single process on
         #  the full batch can be compared with the replicas; world 1 -> no exchange)
@@ -699,7 +726,7 @@ class RetinaPlan(object):
         lst = self.fwd_steps
         self._step(lst, 'mi355_bn_nhwc_stats', ptr(z), c_vp(0), c_vp(0), f32, c_i64(M), c_int(C), c_int(0), ptr(partials))
         self._step(lst, 'mi355_bn_nhwc_reduce', ptr(partials), c_int(nblk.value), c_int(C), ptr(sums), c_vp(0), c_vp(0))
-        if sync and world > 1:
+        if sync and group_exchange(world):
             self._pystep(lst, self._bn_allreduce(sums, group), 'py:bn_allreduce')
         track = bn.track_running_stats and bn.running_mean is not None
         plain = type(bn) is torch.nn.BatchNorm2d            # nn.BatchNorm2d.forward counts batches; the sync class does not
@@ -724,7 +751,7 @@ class RetinaPlan(object):
         self._step(lst, 'mi355_bn_nhwc_stats', ptr(g), ptr(z), ptr(state), f32, c_i64(M), c_int(C), c_int(1), ptr(partials))
         self._step(lst, 'mi355_bn_nhwc_reduce', ptr(partials), c_int(partials.shape[0]), c_int(C), ptr(gsums),
                    ptr(self.grad_view(bn.weight, arena)), ptr(self.grad_view(bn.bias, arena)))
-        if sync and world > 1:
+        if sync and group_exchange(world):
             self._pystep(lst, self._bn_allreduce(gsums, group), 'py:bn_allreduce')
         dz = self.new(tuple(g.shape))
         self._step(lst, 'mi355_bn_nhwc_bwd_apply', ptr(g), ptr(z), ptr(state), ptr(gsums), c_f32(1.0 / (float(M) * world)),

@@ -247,6 +247,7 @@ class Trainer(object):
             # a requires_grad flag flipped: the skip table (pointer + count are by-value arguments of the captured
             # launches) changed: capture the update again
             g2 = torch.cuda.CUDAGraph()
+            self._skip_table(self._g_plan)                     # (the table upload must not fall into the capture)
             torch.cuda.synchronize(dev)
             with torch.cuda.graph(g2, pool=g1.pool()):
                 self._update(self._g_plan, self._s_flag)
