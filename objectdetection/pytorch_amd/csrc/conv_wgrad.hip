@@ -16,6 +16,8 @@
 // architectures/retinanet.py:272-287 (backbone, FPN, heads).
 #include "conv_common.h"
 
+#include <type_traits>
+
 using namespace mi355;
 
 namespace {
@@ -616,6 +618,341 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// ROW3X weight gradient (round 3): the row-of-taps kernel as ONE eight-wave block per CU with a THREE-stage LDS-DMA
+// ring.  Why: the four-wave form above runs two blocks per CU (198 VGPRs, 61.5 KiB), each with one stage of prefetch:
+// its waves sit at the stage-closing barrier / vmcnt(0) for 47-64 % of their cycles (profiles/r01_pmc_sq_waves.txt) and
+// the ablation of DESIGN.md section 4 prices the un-hidden LDS-DMA at 32 of its 138 us on the head towers.  Here the
+// DMA of stage t + 2 is issued while stage t is on the matrix cores (counted `s_waitcnt vmcnt`, raw `s_barrier`, every
+// LDS access of the loop as opaque asm so that hipcc does not drain the DMA queue in front of it: guide section 5,
+// "Pipelining across barriers"), and the eight waves share ONE staging of a 128 k x 128 c x 3-tap tile: 34 KiB of
+// L2 -> LDS fill per stage instead of 2 x 25 KiB for the same 2 x 48 MFMAs per SIMD.
+//   block tile : kernel row r, 128 output channels, 128 input channels, the three column taps
+//   waves      : 2 (k) x 4 (c); a wave owns 64 k x 32 c x 3 taps = 96 accumulator VGPRs, as in the four-wave form
+//   stage      : 64 pixels: dy 64 x 128 k (16 KiB) + activation rows 72 x 128 c (18 KiB; 66 used, row 71 = zeros)
+//   LDS        : 3 stages (102 KiB) + a 1024-entry pixel-row ring (16 KiB, refilled 8 stages at a time)
+// Both LDS images have 256-B rows with the 16-B chunk c at slot c ^ (f(row) << 1), f(row) = row & 3 | bit3(row) << 2:
+// the 8 rows of a 32-lane half of a transposed read (rows r0 .. r0 + 3 and r0 + 8 .. r0 + 11, any r0) then land in 8
+// distinct 32-B bank groups.  Widths dividing the 64-pixel stage only (fixed edge addresses); C % 128 == 0, K >= 128.
+constexpr int X3_TC = 128, X3_XROWS = 72;
+constexpr int X3_DY_BYTES = RM * TK * 2;                    // 16 KiB
+constexpr int X3_STAGE = X3_DY_BYTES + X3_XROWS * X3_TC * 2;    // 34 KiB
+constexpr int X3_NST = 3;
+constexpr int X3_TABN = 1024, X3_TAB_OFF = X3_NST * X3_STAGE;
+constexpr int X3_EPI_LD = X3_TC + 4;
+constexpr int X3_LDS = X3_TAB_OFF + X3_TABN * 16;
+static_assert(TK * X3_EPI_LD * 4 <= X3_TAB_OFF, "epilogue staging must fit in the ring");
+
+typedef int i4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i4v lds_read16(unsigned addr) {
+    i4v v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_write16(unsigned addr, i4v v) {
+    asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ int x3_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+// ABL: diagnostic builds (MI355_X3_ABLATE, tools/bench_head_wgrad.py; 0 = the kernel): 1 no LDS-DMA in the loop, 2 no fragment
+// reads in the loop, 4 no epilogue stores, 8 no MFMAs.  Results are garbage for ABL != 0.
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: scalar branches on the wave index
+    int b = blockIdx.x;
+    const int c_tile = b % L.c_tiles;  b /= L.c_tiles;
+    const int k_tile = b % L.k_tiles;  b /= L.k_tiles;
+    const int kr = b % 3;              b /= 3;          // kernel row of this block
+    const int chunk = b;
+
+    WProb P = L.p[0];
+    int m_begin;
+    if (L.nsorted > 0) {
+        const int pi = L.ch_prob[chunk];
+#pragma unroll
+        for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
+            if (i == pi) P = L.p[i];
+        m_begin = L.ch_mbegin[chunk];
+    } else {
+#pragma unroll
+        for (int i = 1; i < MI355_CONV_MAX_PROBLEMS; ++i)
+            if (i < L.nprob && chunk >= L.p[i].chunk_begin) P = L.p[i];
+        m_begin = (chunk - P.chunk_begin) * L.split_rows;
+    }
+    const int m_end = min(P.M, m_begin + L.split_rows);
+    const int lchunk_id = m_begin / L.split_rows;
+    const int k0 = k_tile * TK, c0 = c_tile * X3_TC;
+    const int dh = P.dh0 + kr;                          // (dhs == 1)
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(P.in, (unsigned)P.in_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_y = make_rsrc(P.dy, (unsigned)P.dy_bytes);
+    const unsigned lds0 = (unsigned)(uintptr_t)(LDS_PTR(void))smem;
+
+    // staging: a DMA wave-instruction fills 4 rows of 256 B; piece pc = 8 i + wave (i = 0, 1) holds rows 4 pc .. 4 pc + 3,
+    // lane -> (row 4 pc + lane / 16, slot lane % 16), source chunk slot ^ (f(row) << 1); f is the same for i = 0, 1.
+    // Activation rows 64 .. 71 (pieces 16, 17): waves 0 and 1.
+    const int srow = 4 * wv + (lane >> 4), slot = lane & 15;
+    const int chunk8 = (slot ^ (x3_f(srow) << 1)) << 3;
+    const int ky = k0 + chunk8, cx = c0 + chunk8;
+    const bool ky_ok = ky + 8 <= L.K;
+    const int xrow2 = 64 + 4 * wv + (lane >> 4);                      // (waves 0, 1)
+    const int cx2 = c0 + ((slot ^ (x3_f(xrow2) << 1)) << 3);
+    const int xdelta = dh * P.W * P.C;
+
+    // pixel-row ring, entry (e + 1) & 1023 <-> pixel m_begin + e, e >= -1:
+    //   .x = element offset of input pixel (n, p, q)   .y = p (or far out of range)   .z = dy row offset / -1
+    const unsigned tab0 = lds0 + X3_TAB_OFF;
+    auto fill = [&](int s0) {                           // entries of stages s0 .. s0 + 7 (e = 64 s0 - 1 .. 64 s0 + 512)
+        for (int i = tid; i < 514; i += 512) {
+            const int e = 64 * s0 + i - 1;
+            const int m = m_begin + e;
+            i4v t = (i4v){0, -0x40000000, -1, 0};
+            if (m >= 0 && m < P.M) {
+                const unsigned n = fdiv((unsigned)m, P.dPQ);
+                const unsigned rem = (unsigned)m - n * (unsigned)(P.P * P.Q);
+                const unsigned p = fdiv(rem, P.dQ);
+                const unsigned q = rem - p * (unsigned)P.Q;
+                t.x = (int)n * P.in_sN + ((int)p * P.W + (int)q) * P.C;
+                t.y = (int)p;
+                if (m < m_end && e >= 0) t.z = (int)n * P.dy_sN + (int)rem * L.K;
+            }
+            lds_write16(tab0 + (unsigned)((e + 1) & (X3_TABN - 1)) * 16u, t);
+        }
+    };
+    // DMA of one stage in two halves: `issue_prep` reads this thread's five pixel-row entries (LDS, asm) and leaves them
+    // pending; `issue_offsets` (behind an lgkmcnt(0)) turns them into buffer offsets; `issue_piece(k)` is one DMA
+    // wave-instruction.  The loop runs the prep beside the MFMAs in front of the stage barrier and spreads the pieces
+    // over the MFMAs behind it: a burst of five pieces + their table reads is ~600 cycles in which neither this wave nor
+    // - after a barrier: in the same phase - its SIMD partner issues an MFMA.
+    i4v tq[5];
+    unsigned doff[5];
+    int dstep = 0;
+    auto issue_prep = [&](int step) {
+        const int eb = 64 * step;                       // ring index of dy row r: eb + r + 1; of activation row j: eb + j
+#pragma unroll
+        for (int i = 0; i < 2; ++i) tq[i] = lds_read16(tab0 + (unsigned)((eb + srow + 32 * i + 1) & (X3_TABN - 1)) * 16u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) tq[2 + i] = lds_read16(tab0 + (unsigned)((eb + srow + 32 * i) & (X3_TABN - 1)) * 16u);
+        tq[4] = lds_read16(tab0 + (unsigned)((eb + xrow2) & (X3_TABN - 1)) * 16u);
+        dstep = step;
+    };
+    auto issue_offsets = [&]() {
+        // every register of the five entries stays allocated until here: hipcc takes an asm output for written when the
+        // statement ends, so a field nobody uses would be handed out as a temporary while the LDS read that fills it is
+        // still in flight (seen: the address of the next table read computed in tq[0].x's register)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) asm volatile("" :: "v"(tq[i]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) doff[i] = (ky_ok && tq[i].z >= 0) ? (unsigned)(tq[i].z + ky) * 2u : OOB_OFFSET;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            doff[2 + i] = (unsigned)(tq[2 + i].y + dh) < (unsigned)P.H ? (unsigned)(tq[2 + i].x + xdelta + cx) * 2u : OOB_OFFSET;
+        doff[4] = (xrow2 < RM + 2 && (unsigned)(tq[4].y + dh) < (unsigned)P.H) ? (unsigned)(tq[4].x + xdelta + cx2) * 2u : OOB_OFFSET;
+    };
+    auto issue_piece = [&](const int k) {               // k = 0, 1: dy; 2, 3: activation rows 0 .. 63; 4: rows 64 .. 71 (waves 0, 1)
+        unsigned char* base = smem + (dstep % X3_NST) * X3_STAGE;
+        if (k < 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (LDS_PTR(void))(base + (8 * k + wv) * 1024), 16, doff[k], 0, 0, 0);
+        else if (k < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_PTR(void))(base + X3_DY_BYTES + (8 * (k - 2) + wv) * 1024), 16, doff[k], 0, 0, 0);
+        else if (wv < 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (LDS_PTR(void))(base + X3_DY_BYTES + (16 + wv) * 1024), 16, doff[4], 0, 0, 0);
+    };
+    auto issue = [&](int step) {                        // the whole stage at once (prologue)
+        issue_prep(step);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        issue_offsets();
+#pragma unroll
+        for (int k = 0; k < 5; ++k) issue_piece(k);
+    };
+
+    f4v acc[3][4][2];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[s3][i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+
+    const int wk = wv >> 2, wc = wv & 3;
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int f = (q4 | ((g & 1) << 2)) << 1;
+    const int row_lo = 8 * g + q4;
+    const int half8 = (p4 & 1) * 8;
+    unsigned ady[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ady[t] = row_lo * 256 + ((8 * wk + 2 * t + (p4 >> 1)) ^ f) * 16 + half8;
+    // activation fragment addresses [sub][h][shift][t]: pixel i = 32 sub + row_lo + 4 h reads staged row i + s;
+    // W | 64 and chunks start at multiples of 64, so the image column of pixel i is i mod W
+    constexpr unsigned ZROW = X3_DY_BYTES + (X3_XROWS - 1) * 256;      // staged row 71: always zeros
+    unsigned adx[2][2][3][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = sub * 32 + row_lo + 4 * h;
+            const int q = i & (P.W - 1);
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int row = i + s3;
+                const bool edge = (s3 == 0 && q == 0) || (s3 == 2 && q == P.W - 1);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int lc = 4 * wc + 2 * t + (p4 >> 1);
+                    adx[sub][h][s3][t] = edge ? ZROW + half8
+                                              : X3_DY_BYTES + row * 256 + ((lc ^ (x3_f(row) << 1)) << 4) + half8;
+                }
+            }
+        }
+
+    const bool do_colsum = P.colsum != nullptr && c_tile == 0 && kr == 0 && wc == 0;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nsteps = (m_end - m_begin + RM - 1) / RM;
+
+    // Fragment registers, double-buffered: while the 24 MFMAs of one 32-pixel group run, the 20 transposed reads of the
+    // NEXT group are issued between them (one read behind each of the first 20 MFMAs: a read + its address add fit the 8
+    // issue cycles a 16x16x32 MFMA leaves free), so a wave never stands at `lgkmcnt(0)` with an idle matrix pipe and
+    // does not depend on its SIMD partner being in the opposite phase.  Raw 8-byte halves until the wait that
+    // retires them; the s8v operands are formed after it.
+    s4v fa0[2][4], fa1[2][4], fb0[2][3][2], fb1[2][3][2];
+    auto read_one = [&](const int buf, const int r, const unsigned sbn, const int subn) {   // r = 0 .. 19, all compile-time
+        if (r < 8) {
+            const int t = r >> 1;
+            const unsigned a = sbn + ady[t] + subn * 8192;
+            if (r & 1) fa1[buf][t] = lds_tr<1024>(a);
+            else       fa0[buf][t] = lds_tr<0>(a);
+        } else {
+            const int rr = r - 8, s3 = rr >> 2, t = (rr >> 1) & 1, h = rr & 1;
+            const unsigned a = sbn + adx[subn][h][s3][t];
+            if (h) fb1[buf][s3][t] = lds_tr<0>(a);
+            else   fb0[buf][s3][t] = lds_tr<0>(a);
+        }
+    };
+    // the 24 MFMAs of group `buf`, with the reads of group (sbn, subn) into the other buffer between them (rd: issue them)
+    auto group = [&](const int buf, auto rd, const unsigned sbn, const int subn, const bool dma) {   // rd: std::true_type / false_type; dma: wave-uniform
+        s8v af[4], bf[3][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            af[t] = (s8v){fa0[buf][t][0], fa0[buf][t][1], fa0[buf][t][2], fa0[buf][t][3],
+                          fa1[buf][t][0], fa1[buf][t][1], fa1[buf][t][2], fa1[buf][t][3]};
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                bf[s3][t] = (s8v){fb0[buf][s3][t][0], fb0[buf][s3][t][1], fb0[buf][s3][t][2], fb0[buf][s3][t][3],
+                                  fb1[buf][s3][t][0], fb1[buf][s3][t][1], fb1[buf][s3][t][2], fb1[buf][s3][t][3]};
+        if (do_colsum) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum[t] += bf16_to_f32((unsigned short)af[t][e]);
+        }
+#pragma unroll
+        for (int m = 0; m < 24; ++m) {
+            const int s3 = m >> 3, i = (m >> 1) & 3, j = m & 1;
+            if constexpr (!(ABL & 8)) acc[s3][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[s3][j], acc[s3][i][j], 0, 0, 0);
+            else { asm volatile("" :: "v"(af[i]), "v"(bf[s3][j])); }
+            if (m < 20) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (decltype(rd)::value && !(ABL & 2)) read_one(buf ^ 1, m, sbn, subn);
+                if ((m & 3) == 1 && dma) issue_piece(m >> 2);       // five pieces behind MFMAs 1, 5, 9, 13, 17
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    fill(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nsteps > 0) issue(0);
+    if (nsteps > 1) issue(1);
+    if (nsteps > 2) issue(2);
+    // stage 0 landed (stages 1, 2 may stay in flight: 4 pieces per wave and stage, 5 for waves 0, 1)
+    if (nsteps > 2)      { if (wv < 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else if (nsteps > 1) { if (wv < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nsteps > 0) {
+#pragma unroll
+        for (int r = 0; r < 20; ++r) read_one(0, r, lds0, 0);
+    }
+    for (int step = 0; step < nsteps; ++step) {
+        const unsigned sb = lds0 + (unsigned)(step % X3_NST) * X3_STAGE;
+        const unsigned sbn = lds0 + (unsigned)((step + 1) % X3_NST) * X3_STAGE;
+        lds_wait();                                                 // group (step, 0) is in buffer 0
+        const bool dma = !(ABL & 1) && step + 3 < nsteps;
+        group(0, std::true_type{}, sb, 1, false);                   // ... and (step, 1) on its way into buffer 1
+        if (dma) issue_prep(step + 3);                              // pixel rows of the stage to issue behind the barrier
+        lds_wait();                                                 // this wave has read stage `step` out
+        if (dma) issue_offsets();
+        // stage step + 1 landed (stage step + 2 may stay in flight)
+        if (step + 2 < nsteps) {
+            if (wv < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                               // every wave: stage step + 1 landed, stage step read out
+        // (the pieces of stage step + 3 go out between the MFMAs of the next group, into the buffer of stage step)
+        // ring entries of stages step + 5 .. step + 12: published by the NEXT iteration's barrier, first read by the
+        // issue_prep of the iteration after that; the slots they replace belong to stages <= step - 3, whose pixel rows
+        // were read four or more iterations ago
+        if (((step + 5) & 7) == 0 && step + 5 < nsteps) fill(step + 5);
+        // (step + 1, 0) on its way into buffer 0; behind the last stage the reads fetch stale LDS bytes into fragments
+        // nobody uses (always inside the allocation): no branch in the MFMA stream
+        group(1, std::true_type{}, sbn, 0, dma);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if (do_colsum) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v = csum[t];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int k = k0 + wk * 64 + t * 16 + (lane & 15);
+            if (lane < 16 && k < L.K) {
+                if (L.slab_stride > 0) P.colsum[(long long)lchunk_id * L.K + k] = v;
+                else atomicAdd(P.colsum + k, v);
+            }
+        }
+    }
+    // ---- epilogue, one column tap at a time through LDS: 512-B contiguous row segments
+    float* epi = reinterpret_cast<float*>(smem);
+    const int fr = lane & 15, fq = lane >> 4;
+    const long long wrow = (long long)L.T * P.C;
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    epi[(wk * 64 + i * 16 + fq * 4 + r) * X3_EPI_LD + wc * 32 + j * 16 + fr] = acc[s3][i][j][r];
+        __syncthreads();
+        const long long coff = (long long)((P.r0 + kr * P.rs) * P.S + (P.s0 + s3 * P.ss)) * P.C + c0 + lane;
+        for (int rr = wv; rr < TK; rr += 8) {
+            const int k = k0 + rr;
+            if (k >= L.K) break;
+            float* dst = P.dw + k * wrow + coff;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float v = epi[rr * X3_EPI_LD + h * 64 + lane];
+                if (ABL & 4) { asm volatile("" :: "v"(v)); continue; }
+                if (L.slab_stride > 0) dst[(long long)lchunk_id * L.slab_stride + h * 64] = v;
+                else atomicAdd(dst + h * 64, v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // MI355_WG_K64=0: K <= 64 layers through the 128-row k-tile forms (A/B)
@@ -791,8 +1128,14 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
     L.k_tiles = (int)cdiv(in.K, TK);
     L.c_tiles = flat ? (int)cdiv((long long)ntaps * C, TC) : (int)cdiv(C, TC);
     if (flat) L.ntaps = 1;
+    // eight-wave ring form (conv_wgrad_row3x_kernel): widths dividing the stage, C % 128 == 0, K >= 128 (MI355_WG_ROW3X=0: off)
+    static const int row3x_on = [] {
+        const char* e = getenv("MI355_WG_ROW3X");
+        return e ? atoi(e) : 1;
+    }();
+    const bool row3x = row3 && !row3_dyn && row3x_on && C % X3_TC == 0 && in.K >= 128;
     if (row3) {
-        L.c_tiles = C / R3_TC;
+        L.c_tiles = C / (row3x ? X3_TC : R3_TC);
         L.ntaps = 3;                                   // kernel rows; a block accumulates the three column taps
     }
     const long long grid = (long long)chunks * L.ntaps * L.k_tiles * L.c_tiles;
@@ -820,7 +1163,29 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
     }
     const dim3 g((unsigned)grid);
     hipStream_t st = (hipStream_t)stream;
-    if (row3) {
+    if (row3x) {
+        static bool x3_attr = false;
+        if (!x3_attr) {
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+            x3_attr = true;
+        }
+        const char* ae = getenv("MI355_X3_ABLATE");               // diagnostic builds (not cached: a bench tool sweeps it)
+        switch (ae ? atoi(ae) : 0) {
+            case 1: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<1>, g, dim3(512), X3_LDS, st, L); break;
+            case 2: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<2>, g, dim3(512), X3_LDS, st, L); break;
+            case 3: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<3>, g, dim3(512), X3_LDS, st, L); break;
+            case 4: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<4>, g, dim3(512), X3_LDS, st, L); break;
+            case 7: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<7>, g, dim3(512), X3_LDS, st, L); break;
+            case 8: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<8>, g, dim3(512), X3_LDS, st, L); break;
+            default: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<0>, g, dim3(512), X3_LDS, st, L);
+        }
+    } else if (row3) {
         static bool r3_attr = false;
         if (!r3_attr) {
             (void)hipFuncSetAttribute((const void*)conv_wgrad_row3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS);

@@ -592,7 +592,7 @@ class RetinaPlan(object):
         L.nprob, L.K, L.T = len(problems), spec.Kpad, spec.T
         slab = spec.Kpad * spec.T * spec.Cpad
         tiles = ops_conv.wgrad_tiles(spec.Kpad, spec.Cpad, spec.T, problems)
-        split = pick_split_rows(rows, tiles, target_blocks=int(os.environ.get('MI355_WG_BLOCKS', '512')),
+        split = pick_split_rows(rows, tiles, target_blocks=ops_conv.wgrad_target_blocks(spec.Kpad, spec.Cpad, spec.T, problems),
                                 min_rows=int(os.environ.get('MI355_WG_MINROWS', '1024')),
                                 granule=int(os.environ.get('MI355_WG_GRANULE', '64')))
         self.keep.append(L)
@@ -641,7 +641,7 @@ class RetinaPlan(object):
         slab = spec0.Kpad * spec0.T * spec0.Cpad
         tiles = ops_conv.wgrad_tiles(spec0.Kpad, spec0.Cpad, spec0.T, problems)
         split = pick_split_rows(sum(g[2] for g in group), tiles,
-                                target_blocks=int(os.environ.get('MI355_WG_BLOCKS', '512')),
+                                target_blocks=ops_conv.wgrad_target_blocks(spec0.Kpad, spec0.Cpad, spec0.T, problems),
                                 min_rows=int(os.environ.get('MI355_WG_MINROWS', '1024')),
                                 granule=int(os.environ.get('MI355_WG_GRANULE', '64')))
         n = len(group)

@@ -168,9 +168,29 @@ def wgrad_row3_ok(problems, cpad, kpad=128):
                and p.Q == p.W and width_ok(p.W) for p in problems)
 
 
+def wgrad_row3x_ok(problems, cpad, kpad):
+    """Launch takes the eight-wave ring form of the row-of-taps kernel (conv_wgrad_row3x_kernel: one block per CU;
+    mirrors the host check in conv_wgrad.hip)."""
+    import os
+    if os.environ.get('MI355_WG_ROW3X', '1') == '0' or cpad % 128 or kpad < 128:
+        return False
+    return wgrad_row3_ok(problems, cpad, kpad) and all(p.W <= 64 and (p.W & (p.W - 1)) == 0 for p in problems)
+
+
+def wgrad_target_blocks(kpad, cpad, taps, problems=None):
+    """Blocks a weight-gradient launch should be cut into: two four-wave blocks per CU, or one eight-wave block per CU
+    for the ring form (MI355_WG_BLOCKS / MI355_WG_X_BLOCKS)."""
+    import os
+    if problems is not None and taps == 9 and wgrad_row3x_ok(problems, cpad, kpad):
+        return int(os.environ.get('MI355_WG_X_BLOCKS', '256'))
+    return int(os.environ.get('MI355_WG_BLOCKS', '512'))
+
+
 def wgrad_tiles(kpad, cpad, taps, problems=None):
     """Output tiles of one pixel chunk of the wgrad launch (mirrors conv_wgrad.hip)."""
     kt = -(-kpad // 128)
+    if problems is not None and taps == 9 and wgrad_row3x_ok(problems, cpad, kpad):
+        return kt * 3 * (cpad // 128)
     if problems is not None and taps == 9 and wgrad_row3_ok(problems, cpad, kpad):
         return kt * 3 * (cpad // 64)
     return kt * (-(-taps * cpad // 128)) if cpad < 128 else kt * taps * (-(-cpad // 128))

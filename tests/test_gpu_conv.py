@@ -288,6 +288,70 @@ def test_conv_wgrad_row_of_taps(dev, case):
     _close(G[:K].reshape(K, R, R, C).permute(0, 3, 1, 2), ref, 2e-3)
 
 
+@pytest.mark.parametrize('case,split', [((2, 32, 32, 128, 256, 3, 1, 1), 128), ((3, 16, 16, 256, 128, 3, 1, 1), 64),
+                                        ((5, 4, 4, 256, 136, 3, 1, 1), 64), ((1, 8, 64, 128, 128, 3, 1, 1), 192),
+                                        ((2, 2, 2, 128, 128, 3, 1, 1), 64), ((3, 1, 1, 256, 256, 3, 1, 1), 64),
+                                        # long chunks: the pixel-row ring of the kernel is refilled every 8 stages
+                                        ((4, 64, 64, 128, 128, 3, 1, 1), 2048), ((2, 64, 32, 128, 384, 3, 1, 1), 1344)])
+def test_conv_wgrad_ring_form(dev, case, split):
+    """conv_wgrad_row3x_kernel (3x3 / stride 1 / same, C % 128 == 0, K >= 128, widths dividing the 64-pixel stage): the
+    eight-wave block with the three-stage LDS-DMA ring.  Against torch's weight gradient, fp32-atomic and slab output
+    (the slab form bit-identical between two launches), chunk lengths from one stage to 32 stages."""
+    from objectdetection.pytorch_amd import ops_conv
+    N, H, W, C, K, R, stride, pad = case
+    x, dy = _mk((N, C, H, W), 21), _mk((N, K, H, W), 22)
+    ref = torch.nn.grad.conv2d_weight(x, (K, C, R, R), dy, stride, pad)
+    kpad = (K + 7) // 8 * 8
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    dyh = torch.zeros((N, H, W, kpad), dtype=torch.bfloat16, device=dev)
+    dyh[..., :K] = dy.permute(0, 2, 3, 1).to(dev).to(torch.bfloat16)
+    pr = ops_conv.fwd_problem(xh, dyh.data_ptr(), R, R, stride, pad, K=kpad)
+    assert ops_conv.wgrad_row3x_ok([pr], C, kpad)
+    cs = torch.zeros(kpad, device=dev)
+    G = ops_conv.conv_wgrad(xh, dyh, R, R, stride, pad, split_rows=split, colsum=cs)
+    _close(G[:K].reshape(K, R, R, C).permute(0, 3, 1, 2), ref, 2e-3)
+    _close(cs[:K], dy.sum((0, 2, 3)), 1e-3)
+    if kpad > K:
+        assert float(G[K:].abs().max()) == 0.0
+    # slab form (what the plans run): per-chunk partial tiles, summed in index order
+    from objectdetection.pytorch_amd._lib import c_i64, c_int, call, ptr, stream_of
+    import ctypes
+    L = ops_conv.ConvLaunch()
+    L.prob[0] = pr
+    L.nprob, L.K, L.T = 1, kpad, 9
+    nsl = -(-(N * H * W) // split)
+    slab = kpad * 9 * C
+    outs = []
+    for _ in range(2):
+        ws = torch.full((nsl, slab), float('nan'), device=dev)
+        cws = torch.zeros((nsl, kpad), device=dev)
+        call('mi355_conv_wgrad_slabs', ctypes.byref(L), ptr(ws), c_i64(slab), c_int(nsl), ptr(cws), c_int(split), stream_of(xh))
+        outs.append((ws.sum(0), cws.sum(0)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    _close(outs[0][0][:K * 9 * C].reshape(K, R, R, C).permute(0, 3, 1, 2), ref, 2e-3)
+    _close(outs[0][1][:K], dy.sum((0, 2, 3)), 1e-3)
+
+
+def test_conv_wgrad_ring_form_grouped_levels(dev):
+    """Five pyramid levels of a shared-weight head conv in ONE ring-form launch (chunks sorted by length)."""
+    from objectdetection.pytorch_amd import ops_conv
+    N, C, K = 2, 256, 256
+    sizes = [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    xs = [_mk((N, C, h, w), 30 + i) for i, (h, w) in enumerate(sizes)]
+    dys = [_mk((N, K, h, w), 40 + i) for i, (h, w) in enumerate(sizes)]
+    keep, probs = [], []
+    for x, dy in zip(xs, dys):
+        xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+        dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+        keep += [xh, dyh]
+        probs.append(ops_conv.fwd_problem(xh, dyh.data_ptr(), 3, 3, 1, 1, K=K))
+    assert ops_conv.wgrad_row3x_ok(probs, C, K)
+    G = torch.zeros((K, 9, C), dtype=torch.float32, device=dev)
+    ops_conv.launch_wgrad(probs, K, 9, G, 128, keep[0])
+    ref = sum(torch.nn.grad.conv2d_weight(x, (K, C, 3, 3), dy, 1, 1) for x, dy in zip(xs, dys))
+    _close(G.reshape(K, 3, 3, C).permute(0, 3, 1, 2), ref, 2e-3)
+
+
 def test_grouped_heads_shared_weights(dev):
     """Five pyramid levels, one launch, outputs concatenated along A (retinanet.py:285-287)."""
     from objectdetection.pytorch_amd import ops_conv
