@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
 constexpr int X3_TC = 128, X3_XROWS = 72;
 constexpr int X3_DY_BYTES = RM * TK * 2;                    // 16 KiB
 constexpr int X3_STAGE = X3_DY_BYTES + X3_XROWS * X3_TC * 2;    // 34 KiB
-constexpr int X3_NST = 3;
+constexpr int X3_NST = 4;                                   // ring depth: X3_NST - 1 stages in flight beside the one on the matrix cores
 constexpr int X3_TABN = 1024, X3_TAB_OFF = X3_NST * X3_STAGE;
 constexpr int X3_EPI_LD = X3_TC + 4;
 constexpr int X3_LDS = X3_TAB_OFF + X3_TABN * 16;
@@ -868,13 +868,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
     fill(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (nsteps > 0) issue(0);
-    if (nsteps > 1) issue(1);
-    if (nsteps > 2) issue(2);
-    // stage 0 landed (stages 1, 2 may stay in flight: 4 pieces per wave and stage, 5 for waves 0, 1)
-    if (nsteps > 2)      { if (wv < 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-    else if (nsteps > 1) { if (wv < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-    else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // prologue: the first X3_NST stages; stage 0 landed (the others may stay in flight: 4 pieces per wave and stage, 5 for
+    // waves 0, 1)
+#pragma unroll
+    for (int i = 0; i < X3_NST; ++i)
+        if (nsteps > i) issue(i);
+    {
+        const int fly = min(nsteps, X3_NST) - 1;                    // stages that may stay in flight
+        auto wait_stages = [&](const int n) {                       // n wave-uniform
+            if (n <= 0)      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (n == 1) { if (wv < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else if (n == 2) { if (wv < 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else             { if (wv < 2) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+        };
+        wait_stages(fly);
+    }
     __builtin_amdgcn_s_barrier();
     if (nsteps > 0) {
 #pragma unroll
@@ -884,24 +892,24 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
         const unsigned sb = lds0 + (unsigned)(step % X3_NST) * X3_STAGE;
         const unsigned sbn = lds0 + (unsigned)((step + 1) % X3_NST) * X3_STAGE;
         lds_wait();                                                 // group (step, 0) is in buffer 0
-        const bool dma = !(ABL & 1) && step + 3 < nsteps;
+        const bool dma = !(ABL & 1) && step + X3_NST < nsteps;
         group(0, std::true_type{}, sb, 1, false);                   // ... and (step, 1) on its way into buffer 1
-        if (dma) issue_prep(step + 3);                              // pixel rows of the stage to issue behind the barrier
+        if (dma) issue_prep(step + X3_NST);                         // pixel rows of the stage to issue behind the barrier
         lds_wait();                                                 // this wave has read stage `step` out
         if (dma) issue_offsets();
-        // stage step + 1 landed (stage step + 2 may stay in flight)
-        if (step + 2 < nsteps) {
-            if (wv < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stage step + 1 landed (stages step + 2 .. step + X3_NST - 1 may stay in flight)
+        {
+            const int fly = min(nsteps - step - 2, X3_NST - 2);
+            if (fly <= 0)      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (fly == 1) { if (wv < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else               { if (wv < 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
         }
         __builtin_amdgcn_s_barrier();                               // every wave: stage step + 1 landed, stage step read out
-        // (the pieces of stage step + 3 go out between the MFMAs of the next group, into the buffer of stage step)
-        // ring entries of stages step + 5 .. step + 12: published by the NEXT iteration's barrier, first read by the
-        // issue_prep of the iteration after that; the slots they replace belong to stages <= step - 3, whose pixel rows
-        // were read four or more iterations ago
-        if (((step + 5) & 7) == 0 && step + 5 < nsteps) fill(step + 5);
+        // (the pieces of stage step + X3_NST go out between the MFMAs of the next group, into the buffer of stage step)
+        // ring entries of stages step + 6 .. step + 13: published by the NEXT iteration's barrier, first read by the
+        // issue_prep of the iteration after that; the slots they replace belong to stages <= step - 2, whose pixel rows
+        // were read five or more iterations ago
+        if (((step + 6) & 7) == 0 && step + 6 < nsteps) fill(step + 6);
         // (step + 1, 0) on its way into buffer 0; behind the last stage the reads fetch stale LDS bytes into fragments
         // nobody uses (always inside the allocation): no branch in the MFMA stream
         group(1, std::true_type{}, sbn, 0, dma);
