@@ -50,7 +50,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--depth', type=int, default=50)
     ap.add_argument('--arch', default='retinanet',
-                    help="'retinanet' (headline), 'efficientdet-dN' (configs[3], [4]) or 'ksevendet' / 'ksevendet-panet' (SURVEY 8 f-3)")
+                    help="'retinanet' (headline), 'efficientdet-dN' (configs[3], [4]) or 'ksevendet' / 'ksevendet-panet' / 'ksevendet-bifpn' (SURVEY 8 f-3)")
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -75,18 +75,19 @@ def parse():
 
 
 def build_model(depth, num_classes, dev, arch='retinanet', precision='bf16', sync_bn=False):
-    if arch not in ('retinanet', 'ksevendet', 'ksevendet-panet') and not arch.startswith('efficientdet-d'):
-        raise SystemExit("--arch must be 'retinanet', 'ksevendet[-panet]' or 'efficientdet-dN', got %r" % arch)
+    if arch not in ('retinanet', 'ksevendet', 'ksevendet-panet', 'ksevendet-bifpn') and not arch.startswith('efficientdet-d'):
+        raise SystemExit("--arch must be 'retinanet', 'ksevendet[-panet|-bifpn]' or 'efficientdet-dN', got %r" % arch)
     if arch.startswith('ksevendet'):
         # config/model/ksevendet_resnet.yaml (ResNet trunk of --depth, FPN or PANet-FPN neck, simple heads
         # with per-level BN over shared convs), frozen BN as train_ksevendet.py runs it
         import yaml
         from objectdetection.pytorch_amd.ksevendet.architecture import ksevendet
         cfg = yaml.safe_load(open(os.path.join(ROOT, 'objectdetection', 'pytorch_amd', 'config', 'model',
-                                               'ksevendet_resnet.yaml')))
+                                               'ksevendet_resnet_bifpn.yaml' if arch.endswith('bifpn') else 'ksevendet_resnet.yaml')))
         cfg.pop('architecture')
         cfg['variant'] = 'resnet%d' % depth
-        cfg['neck'] = 'panet-fpn' if arch.endswith('panet') else 'fpn'
+        if not arch.endswith('bifpn'):            # (ksevendet_resnet_bifpn.yaml: BiFPN neck, unshared heads on levels 3..5)
+            cfg['neck'] = 'panet-fpn' if arch.endswith('panet') else 'fpn'
         model = ksevendet.KSevenDet(cfg, num_classes=num_classes, pretrained=False)
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
         sd = synth.synth_state_dict(shapes, seed=0, gain=0.78 if depth >= 50 else 0.87)
@@ -391,7 +392,7 @@ def main():
     num_classes = 80
     model, sd = build_model(args.depth, num_classes, dev, args.arch, args.precision, args.sync_bn)
     name = ('RetinaNet-R%d' % args.depth if args.arch == 'retinanet' else
-            'KSevenDet-R%d-%s' % (args.depth, 'PANetFPN' if args.arch.endswith('panet') else 'FPN') if args.arch.startswith('ksevendet')
+            'KSevenDet-R%d-%s' % (args.depth, 'PANetFPN' if args.arch.endswith('panet') else 'BiFPN' if args.arch.endswith('bifpn') else 'FPN') if args.arch.startswith('ksevendet')
             else 'EfficientDet-D' + args.arch[-1])
     B, S = args.batch, args.size
     # each rank owns its shard of the global batch (weak scaling: per-GPU batch fixed)

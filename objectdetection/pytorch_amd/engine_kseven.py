@@ -76,13 +76,46 @@ class KSevenPlan(RetinaPlan):
         nlev = len(m.head_feature_pyramid_levels)
 
         def head(mod, name):
-            tower = [[add('%s.conv_tower.0.%d@p%d' % (name, i, lv), mod.conv_tower[0][i], mod.bn_modules[lv][i])
-                      for lv in range(nlev)] for i in range(mod.layers_num)]
-            out = add(name + '.header.0', mod.header[0])
-            out.Kpad = -(-out.K // 64) * 64            # gradient-side pitch (see RetinaPlan._collect_layers)
-            return tower, out
+            return self._head_specs(add, mod, name, nlev)
         self.reg_tower, self.reg_out = head(m.regressor, 'regressor')
         self.cls_tower, self.cls_out = head(m.classifier, 'classifier')
+
+    @staticmethod
+    def _head_specs(add, mod, name, nlev):
+        """(tower[layer][level], header[level]) specs of a simple head: shared weights (simple_head.py:116-119: one conv per
+        layer, a folded shadow per level BN; ONE header spec for all levels) or a tower and a header per level (:120-127)."""
+        share = bool(mod.share_weights)
+        tower = [[add('%s.conv_tower.%d.%d@p%d' % (name, 0 if share else lv, i, lv), mod.conv_tower[0 if share else lv][i],
+                      mod.bn_modules[lv][i]) for lv in range(nlev)] for i in range(mod.layers_num)]
+        if share:
+            out = add(name + '.header.0', mod.header[0])
+            outs = [out] * nlev
+        else:
+            outs = [add('%s.header.%d' % (name, lv), mod.header[lv]) for lv in range(nlev)]
+        for o in outs:
+            o.Kpad = -(-o.K // 64) * 64                # gradient-side pitch (see RetinaPlan._collect_layers)
+        return tower, outs
+
+    def _head_out_levels(self, specs, xs, out, kout, act):
+        """Header conv of every level writing fp32 straight into [B, A, .]: one grouped launch; unshared headers bring their
+        own weights / bias per problem (Mi355ConvProblem.weight)."""
+        if all(s is specs[0] for s in specs):
+            return RetinaPlan._head_out_fwd(self, specs[0], xs, out, kout, act)
+        per_img = self.ncells * kout
+        probs = []
+        for sp, x, off in zip(specs, xs, self.cell_off):
+            w = x.shape[2]
+            pr = fwd_problem(x, out.data_ptr() + 4 * off * kout, 3, 3, 1, 1, out_strides=(per_img, w * kout, kout), K=kout)
+            pr.weight = sp.w_fwd.data_ptr()
+            pr.bias = 0 if sp.conv.bias is None else sp.conv.bias.data_ptr()
+            probs.append(pr)
+            self.fwd_launches.append((sp, [(x.shape[0], x.shape[1], x.shape[2])]))
+        if self.prec == 'fp32' or len(probs) > ops_conv.MAX_PROBLEMS:      # (per-problem weights are a bf16-launch feature)
+            for sp, pr in zip(specs, probs):
+                pr.weight = pr.bias = 0
+                self._gather(self.fwd_steps, [pr], sp.w_fwd, kout, 9, bias=sp.conv.bias, act=act, out_f32=True)
+            return
+        self._gather(self.fwd_steps, probs, specs[0].w_fwd, kout, 9, bias=specs[0].conv.bias, act=act, out_f32=True)
 
     # ------------------------------------------------------------------ pyramid: + PANet bottom-up path
     def _fpn_fwd(self, feats):
@@ -124,10 +157,10 @@ class KSevenPlan(RetinaPlan):
         self.cls = self.new((B, self.A, C), torch.float32)
         self._mark_side = True                         # the box head runs beside the class head (side stream)
         self.reg_t = self._tower_fwd(self.reg_tower)
-        self._head_out_fwd(self.reg_out, self.reg_t[-1], self.reg, 4 * self.A_cell, ACT_NONE)
+        self._head_out_levels(self.reg_out, self.reg_t[-1], self.reg, 4 * self.A_cell, ACT_NONE)
         self._mark_side = False
         self.cls_t = self._tower_fwd(self.cls_tower)
-        self._head_out_fwd(self.cls_out, self.cls_t[-1], self.cls, C * self.A_cell, ACT_SIGMOID)
+        self._head_out_levels(self.cls_out, self.cls_t[-1], self.cls, C * self.A_cell, ACT_SIGMOID)
         self.losses = self.new((2,), torch.float32)
         self.argmax = self.new((B, self.A), torch.int32)
         self.state = self.new((B, self.A), torch.int8)
@@ -176,7 +209,7 @@ class KSevenPlan(RetinaPlan):
 
     def _heads_bwd(self):
         B = self.B
-        kc, kr = self.cls_out.Kpad, self.reg_out.Kpad
+        kc, kr = self.cls_out[0].Kpad, self.reg_out[0].Kpad
         self.gcls = self.new((B, self.ncells, kc), zero=True)
         self.greg = self.new((B, self.ncells, kr), zero=True)
         self.cls_pitch, self.reg_pitch = kc, kr
@@ -185,8 +218,10 @@ class KSevenPlan(RetinaPlan):
         self._head_bwd(self.cls_out, self.cls_tower, self.cls_t, self.gcls, kc, g_feat, first=False)
         return g_feat
 
-    def _head_bwd(self, out_spec, tower, acts, gout, kp, g_feat, first):
+    def _head_bwd(self, out_specs, tower, acts, gout, kp, g_feat, first):
         B = self.B
+        out_spec = out_specs[0]
+        shared_out = all(s is out_spec for s in out_specs)
         xs = acts[-1]
         F = xs[0].shape[-1]                            # head feature width
         wprobs, dprobs, gys = [], [], []
@@ -207,8 +242,18 @@ class KSevenPlan(RetinaPlan):
             dp.out_sN, dp.out_sH, dp.out_sW = h * w * F, w * F, F
             dp.in_sN = self.ncells * kp
             dprobs.append(dp)
-        self._wgrad(wprobs, out_spec, B * self.ncells)
-        self._gather(self.bwd_steps, dprobs, out_spec.w_dgr, F, 9)
+        if shared_out:
+            self._wgrad(wprobs, out_spec, B * self.ncells)
+            self._gather(self.bwd_steps, dprobs, out_spec.w_dgr, F, 9)
+        elif self.prec == 'fp32' or len(dprobs) > ops_conv.MAX_PROBLEMS:
+            for sp, wp, dp, x in zip(out_specs, wprobs, dprobs, xs):
+                self._wgrad([wp], sp, B * x.shape[1] * x.shape[2])
+                self._gather(self.bwd_steps, [dp], sp.w_dgr, F, 9)
+        else:                                           # a header per level: per-spec workspaces, per-problem w_dgr
+            self._wgrad_multi([(wp, sp, B * x.shape[1] * x.shape[2]) for sp, wp, x in zip(out_specs, wprobs, xs)])
+            for sp, dp in zip(out_specs, dprobs):
+                dp.weight, dp.bias = sp.w_dgr.data_ptr(), 0
+            self._gather(self.bwd_steps, dprobs, out_spec.w_dgr, F, 9)
         for li in range(len(tower) - 1, -1, -1):
             ins = acts[li - 1] if li > 0 else self.levels
             nxt = []

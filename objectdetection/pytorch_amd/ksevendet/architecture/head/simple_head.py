@@ -1,8 +1,9 @@
 """Parameter containers mirroring ksevendet/architecture/head/simple_head.py: `Regressor` (:78-174) and
 `Classifier` (:177-315) in their default form (head_type 'simple', act_type 'relu'): `layers_num` x
-[3x3 conv shared over the pyramid levels -> PER-LEVEL BatchNorm(momentum 0.01, eps 1e-3) -> ReLU] + a shared
-3x3 header conv; the classifier ends in a sigmoid (:313).  State_dict keys as the reference: conv_tower.0.i,
-header.0, bn_modules.level.layer.  The arithmetic (per-level frozen-BN fold over the shared weights, or
+[3x3 conv -> PER-LEVEL BatchNorm(momentum 0.01, eps 1e-3) -> ReLU] + a 3x3 header conv; the classifier ends in a
+sigmoid (:313).  `share_weights=True` (config/model/ksevendet_resnet.yaml): one tower and one header shared by the pyramid
+levels; `share_weights=False` (ksevendet_resnet_bifpn.yaml; :120-127): a tower and a header per level.  State_dict keys as
+the reference: conv_tower.t.i, header.t, bn_modules.level.layer (t = 0, or the level).  The arithmetic (per-level frozen-BN fold over the shared weights, or
 batch-statistics passes when the BN is in train mode) runs in engine_kseven.KSevenPlan."""
 import math
 
@@ -18,9 +19,9 @@ class _SimpleHead(_PlanOnly):
         assert head_type in ['simple', 'efficient']
         assert act_type in ['relu', 'swish']
         super(_SimpleHead, self).__init__()
-        if head_type != 'simple' or act_type != 'relu' or not share_weights:
-            raise NotImplementedError("only head_type='simple', act_type='relu', share_weights=True (the defaults of "
-                                      "config/model/ksevendet_resnet.yaml) are built on the MI355X path")
+        if head_type != 'simple' or act_type != 'relu':
+            raise NotImplementedError("only head_type='simple', act_type='relu' (config/model/ksevendet_resnet*.yaml) are "
+                                      "built on the MI355X path")
         if conv_kernel_size != 3 or conv_stride != 1 or conv_padding != 1:
             raise NotImplementedError('head convs other than 3x3 / stride 1 / pad 1 are not built')
         self.convert_onnx = False
@@ -34,10 +35,12 @@ class _SimpleHead(_PlanOnly):
             logger.info('Head Type     : %s (%s + %s)' % (what, head_type, act_type))
             logger.info('Features Num  : %d' % features_num)
             logger.info('Layers Num    : %d' % layers_num)
+        ntow = 1 if share_weights else num_pyramid_levels    # simple_head.py:116-127
         self.conv_tower = nn.ModuleList([nn.ModuleList(
             [nn.Conv2d(in_features_num if i == 0 else features_num, features_num, kernel_size=3, stride=1, padding=1)
-             for i in range(layers_num)])])
-        self.header = nn.ModuleList([nn.Conv2d(features_num, out_channels, kernel_size=3, stride=1, padding=1)])
+             for i in range(layers_num)]) for _ in range(ntow)])
+        self.header = nn.ModuleList([nn.Conv2d(features_num, out_channels, kernel_size=3, stride=1, padding=1)
+                                     for _ in range(ntow)])
         self.bn_modules = nn.ModuleList(
             [nn.ModuleList([nn.BatchNorm2d(features_num, momentum=0.01, eps=1e-3) for i in range(layers_num)])
              for j in range(num_pyramid_levels)])

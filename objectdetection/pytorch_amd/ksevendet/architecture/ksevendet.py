@@ -4,18 +4,19 @@ builds from a YAML model config (config/model/ksevendet_resnet.yaml).
 Same constructor (`KSevenDet(cfg, num_classes=80, iou_threshold=0.5, **kwargs)`), attribute tree and state_dict
 keys (backbone.*, neck.*, regressor.*, classifier.*), same `forward(img_batch, annotations=None,
 return_head=False, return_loss=False)` contract (:197-286).  Built: `backbone: resnet` (variant resnet18/34/50/
-101/152), `neck: fpn` and `neck: panet-fpn` (PANetFPN, :45-59), the simple shared heads with per-level BatchNorm.
-Other backbones / BiFPN necks raise NotImplementedError.  The modules hold parameters; the forward is one launch
+101/152), `neck: fpn` and `neck: panet-fpn` (PANetFPN, :45-59), `neck: bifpn` (BiFPN, :64-86; config/model/
+ksevendet_resnet_bifpn.yaml), the simple heads with per-level BatchNorm, shared over the levels or one per level.
+Other backbones and the `tfdbifpn` neck raise NotImplementedError.  The modules hold parameters; the forward is one launch
 plan (engine_kseven.KSevenPlan), exposed to autograd as a single node like architectures/retinanet.py."""
 import torch.nn as nn
 
-from ... import engine_kseven
+from ... import engine_kseven, engine_kseven_bifpn
 from ...architectures import retinanet as _retina
 from .anchors import Anchors
 from .backbone import registry
 from .head import Classifier, Regressor
 from .losses import FocalLoss
-from .neck import PANetFPN
+from .neck import BiFPN, PANetFPN
 from .utils import BBoxTransform, ClipBoxes
 
 
@@ -41,9 +42,16 @@ class KSevenDet(nn.Module):
             self.neck = PANetFPN(feature_channels, in_pyramid_levels=self.backbone_feature_pyramid_levels,
                                  out_pyramid_levels=self.neck_feature_pyramid_levels, features_num=fpn_features_num,
                                  panet_buttomup=cfg['neck'] == 'panet-fpn', logger=logger)
-        elif cfg['neck'] in ('bifpn', 'tfdbifpn'):
-            raise NotImplementedError("neck '%s' (ksevendet/architecture/neck/bifpn.py) is not built on the MI355X path"
-                                      % cfg['neck'])
+        elif cfg['neck'] == 'bifpn':                        # ksevendet.py:64-86
+            self.neck = BiFPN(feature_channels, in_pyramid_levels=self.backbone_feature_pyramid_levels,
+                              neck_pyramid_levels=self.neck_feature_pyramid_levels,
+                              out_pyramid_levels=self.head_feature_pyramid_levels, features_num=fpn_features_num,
+                              repeats=cfg['neck_config']['bifpn_repeats'], attention=cfg['neck_config']['bifpn_attention'],
+                              logger=logger)
+            self._plan_class = engine_kseven_bifpn.KSevenBiFPNPlan
+        elif cfg['neck'] == 'tfdbifpn':
+            raise NotImplementedError("neck 'tfdbifpn' (ksevendet/architecture/neck/bifpn.py:400-, a stack of TFDBiFPN cells) "
+                                      "is not built on the MI355X path")
         else:
             raise ValueError('Unknown neck %s' % cfg['neck'])
         if list(self.backbone_feature_pyramid_levels) != [3, 4, 5] or list(self.neck_feature_pyramid_levels) != [3, 4, 5, 6, 7]:

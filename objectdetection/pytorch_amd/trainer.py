@@ -136,7 +136,7 @@ class Trainer(object):
         RCCL stream as soon as the backward pass has finished it (heads, pyramid, layer4, ... in that
         order), while the remaining backward launches keep the compute stream busy."""
         from . import engine
-        pc = getattr(type(self.model), '_plan_class', None)      # (EfficientDet's tape-built backward: one exchange)
+        pc = getattr(self.model, '_plan_class', None)            # (EfficientDet's / BiFPN's tape-built backward: one exchange)
         import os
         # (MI355_FORCE_OVERLAP=1: take this path on a world-size-1 process group too, to rehearse the exchange
         #  against the real RCCL stream machinery on one GPU: tools/nccl_rehearse.py)

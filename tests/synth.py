@@ -8,6 +8,8 @@ box (where /root/reference does not exist).  Input contract follows the referenc
 """
 import zlib
 
+import re
+
 import numpy as np
 
 
@@ -77,7 +79,8 @@ def synth_state_dict(shapes, seed=0, head_std=0.01, prior=0.01, gain=1.0):
             out[key] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
         elif len(shape) == 4:
             o, i, kh, kw = shape
-            if key.endswith('Model.output.weight') or '.header.pointwise_conv.' in key or key.endswith('.header.0.weight'):
+            if key.endswith('Model.output.weight') or '.header.pointwise_conv.' in key or \
+                    re.search(r'\.header\.\d+\.weight$', key):          # (KSevenDet: header.0, or one header per level)
                 std = head_std
             elif i == 1 or 'depthwise' in key:      # depthwise: fan = kh*kw
                 std = np.sqrt(2.0 / (kh * kw))
@@ -89,8 +92,8 @@ def synth_state_dict(shapes, seed=0, head_std=0.01, prior=0.01, gain=1.0):
         elif len(shape) == 1 and leaf == 'weight':   # BN gamma
             out[key] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
         elif len(shape) == 1 and leaf == 'bias':
-            if key in ('classificationModel.output.bias', 'classifier.header.pointwise_conv.conv.bias',
-                       'classifier.header.0.bias'):
+            if key in ('classificationModel.output.bias', 'classifier.header.pointwise_conv.conv.bias') or \
+                    re.match(r'classifier\.header\.\d+\.bias$', key):
                 out[key] = np.full(shape, -np.log((1.0 - prior) / prior), dtype=np.float32)
             else:
                 out[key] = (0.1 * rng.standard_normal(shape)).astype(np.float32)

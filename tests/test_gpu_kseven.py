@@ -1,5 +1,5 @@
 """GPU: the KSevenDet family (ksevendet/architecture/ksevendet.py:20-301) on its launch plan against
-goldens computed with the reference's own neck (neck/fpn.py PANetFPN), heads (head/simple_head.py: shared convs +
+goldens computed with the reference's own necks (neck/fpn.py PANetFPN, neck/bifpn.py BiFPN), heads (head/simple_head.py: shared convs +
 per-level BN) and anchors files, wired as ksevendet.py:197-231 (tools/make_golden.py:gen_e2e_kseven explains why the
 package itself cannot be imported).  fp32 mode at the north-star bounds, bf16 mode at bf16 bounds."""
 import os
@@ -15,11 +15,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def kseven_cfg(neck):
+    """The YAML model config a golden was made with (tools/make_golden.py:gen_e2e_kseven): ksevendet_resnet.yaml with the
+    neck switched, or ksevendet_resnet_bifpn.yaml ('bifpn2': two repeats, heads on all five neck levels)."""
+    name = 'ksevendet_resnet_bifpn.yaml' if neck.startswith('bifpn') else 'ksevendet_resnet.yaml'
+    cfg = yaml.safe_load(open(os.path.join(ROOT, 'objectdetection', 'pytorch_amd', 'config', 'model', name)))
+    assert cfg.pop('architecture') == 'ksevendet'
+    if neck == 'bifpn2':
+        cfg['neck_config']['bifpn_repeats'] = 2
+        cfg['head_feature_pyramid_levels'] = [3, 4, 5, 6, 7]
+    elif not neck.startswith('bifpn'):
+        cfg['neck'] = neck
+    return cfg
+
+
 def build(g, dev, precision):
     from objectdetection.pytorch_amd.ksevendet.architecture import ksevendet
-    cfg = yaml.safe_load(open(os.path.join(ROOT, 'objectdetection', 'pytorch_amd', 'config', 'model', 'ksevendet_resnet.yaml')))
-    assert cfg.pop('architecture') == 'ksevendet'
-    cfg['neck'] = str(g['neck'])
+    cfg = kseven_cfg(str(g['neck']))
     model = ksevendet.KSevenDet(cfg, num_classes=int(g['num_classes']), pretrained=False)
     model.precision = precision
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -38,7 +50,8 @@ def build(g, dev, precision):
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-@pytest.mark.parametrize('tag', ['kseven_r18_fpn_128x160', 'kseven_r18_panet_128', 'kseven_r18_headbn_128'])
+@pytest.mark.parametrize('tag', ['kseven_r18_fpn_128x160', 'kseven_r18_panet_128', 'kseven_r18_headbn_128',
+                                 'kseven_r18_bifpn_128x256', 'kseven_r18_bifpn2_128'])
 def test_kseven_vs_reference_golden(golden_dir, tag, precision):
     g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
     dev = torch.device('cuda', 0)
@@ -107,7 +120,7 @@ def test_kseven_trainer_step(golden_dir):
     np.testing.assert_allclose(l0.cpu().numpy(), [g['cls_loss'].item(), g['reg_loss'].item()], rtol=4e-2)
 
 
-@pytest.mark.parametrize('tag', ['kseven_r18_fpn_128x160', 'kseven_r18_panet_128'])
+@pytest.mark.parametrize('tag', ['kseven_r18_fpn_128x160', 'kseven_r18_panet_128', 'kseven_r18_bifpn_128x256'])
 def test_kseven_gradients_are_bit_reproducible(golden_dir, tag):
     """The tower convs are shared by the five levels (each with its own folded BN): their dW is the sum of five per-level
     contributions, added in chain order by the parameter-gradient table (Mi355LayerDesc.share_next), not by atomics."""

@@ -142,7 +142,8 @@ def test_package_import_raises_hw_queue_count():
     assert out.stdout.strip() == '5'
 
 
-@pytest.mark.parametrize('tag,neck', [('kseven_r18_fpn_128x160', 'fpn'), ('kseven_r18_panet_128', 'panet-fpn')])
+@pytest.mark.parametrize('tag,neck', [('kseven_r18_fpn_128x160', 'fpn'), ('kseven_r18_panet_128', 'panet-fpn'),
+                                      ('kseven_r18_bifpn_128x256', 'bifpn'), ('kseven_r18_bifpn2_128', 'bifpn2')])
 def test_ksevendet_state_dict_and_config_contract(golden_dir, tag, neck):
     """`KSevenDet(cfg, num_classes, pretrained=False)` as train_ksevendet.py:85-89, :207 builds it from
     the YAML model config; state_dict keys / shapes equal those of the reference modules the golden was made with
@@ -151,21 +152,31 @@ def test_ksevendet_state_dict_and_config_contract(golden_dir, tag, neck):
     from objectdetection.pytorch_amd.ksevendet.architecture import ksevendet
     from objectdetection.pytorch_amd.ksevendet.architecture.backbone import registry
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cfg = yaml.safe_load(open(os.path.join(root, 'objectdetection', 'pytorch_amd', 'config', 'model', 'ksevendet_resnet.yaml')))
+    bifpn = neck.startswith('bifpn')
+    cfg = yaml.safe_load(open(os.path.join(root, 'objectdetection', 'pytorch_amd', 'config', 'model',
+                                           'ksevendet_resnet_bifpn.yaml' if bifpn else 'ksevendet_resnet.yaml')))
     assert cfg.pop('architecture') == 'ksevendet'
-    cfg['neck'] = neck
+    if neck == 'bifpn2':                      # two BiFPN repeats, heads on all five neck levels (as the golden)
+        cfg['neck_config']['bifpn_repeats'] = 2
+        cfg['head_feature_pyramid_levels'] = [3, 4, 5, 6, 7]
+    elif not bifpn:
+        cfg['neck'] = neck
     g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
     model = ksevendet.KSevenDet(cfg, num_classes=int(g['num_classes']), pretrained=False)
     sd = model.state_dict()
     assert list(sd.keys()) == [str(k) for k in g['state_keys']]
     assert [','.join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g['state_shapes']]
-    assert model.anchors.num_anchors_per_cell == 6 and list(model.anchors.sizes) == [32, 64, 128, 256, 512]
+    assert model.anchors.num_anchors_per_cell == 6
+    assert list(model.anchors.sizes) == [32, 64, 128, 256, 512][:len(cfg.get('head_feature_pyramid_levels', [3, 4, 5, 6, 7]))]
     assert all(not m.training for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d))    # ksevendet.py:164
     assert registry.is_model('resnet50') and 'resnet18' in registry._module_to_models['resnet']
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 3, 128, 128), torch.zeros(1, 1, 5), return_loss=True)                # no CPU fallback
-    bad = dict(cfg, neck='bifpn')
-    with pytest.raises(NotImplementedError):
-        ksevendet.KSevenDet(bad, num_classes=3)
+    with pytest.raises(NotImplementedError):   # a stack of TFDBiFPN cells (ksevendet.py:87-104): not built
+        ksevendet.KSevenDet(dict(cfg, neck='tfdbifpn', neck_config=dict(cfg['neck_config'], bifpn_repeats=1, bifpn_attention=False)),
+                            num_classes=3)
+    if bifpn:                                  # the reference's attention path cannot run either (neck/bifpn.py:372)
+        with pytest.raises(NotImplementedError):
+            ksevendet.KSevenDet(dict(cfg, neck_config=dict(cfg['neck_config'], bifpn_attention=True)), num_classes=3)
     with pytest.raises(NotImplementedError):
         ksevendet.KSevenDet(dict(cfg, head_config=dict(cfg['head_config'], act_type='swish')), num_classes=3)

@@ -474,8 +474,21 @@ def gen_e2e_kseven(neck, H, W, B, num_classes, tag, gain, train_bn_heads=False):
     fpn_mod = _load_by_path('ref_ks_fpn', root + 'neck/fpn.py')
     head_mod = _load_by_path('ref_ks_head', root + 'head/simple_head.py')
     anc_mod = _load_by_path('ref_ks_anchors', root + 'anchors.py')
-    cfg = yaml.safe_load(open('/root/reference/config/model/ksevendet_resnet.yaml'))
-    assert cfg['variant'] == 'resnet18' and cfg['neck'] == 'fpn'
+    bifpn = neck.startswith('bifpn')
+    if bifpn:
+        # SURVEY 8 f-3, the BiFPN neck: ksevendet/architecture/neck/bifpn.py (BiFPN / BiFPNModule / SeparableConvBlock) with
+        # the values of config/model/ksevendet_resnet_bifpn.yaml (features 128, unshared simple heads, head levels [3, 4, 5]);
+        # 'bifpn2' = two repeats and all five neck levels handed to the heads (first_time / last_time modules both kinds)
+        bifpn_mod = _load_by_path('ref_ks_bifpn', root + 'neck/bifpn.py')
+        cfg = yaml.safe_load(open('/root/reference/config/model/ksevendet_resnet_bifpn.yaml'))
+        assert cfg['variant'] == 'resnet18' and cfg['neck'] == 'bifpn' and not cfg['neck_config']['bifpn_attention']
+        if neck == 'bifpn2':
+            cfg['neck_config']['bifpn_repeats'] = 2
+            cfg['head_feature_pyramid_levels'] = [3, 4, 5, 6, 7]
+    else:
+        cfg = yaml.safe_load(open('/root/reference/config/model/ksevendet_resnet.yaml'))
+        assert cfg['variant'] == 'resnet18' and cfg['neck'] == 'fpn'
+    head_levels = cfg.get('head_feature_pyramid_levels', cfg['neck_feature_pyramid_levels']) if bifpn else cfg['neck_feature_pyramid_levels']
     torch.manual_seed(0)
 
     class RefKSeven(torch.nn.Module):
@@ -484,16 +497,23 @@ def gen_e2e_kseven(neck, H, W, B, num_classes, tag, gain, train_bn_heads=False):
             self.backbone = ref_retinanet.retinanet18(num_classes)          # trunk only: conv1 .. layer4
             for name in ('fpn', 'regressionModel', 'classificationModel', 'anchors', 'focalLoss', 'regressBoxes', 'clipBoxes'):
                 delattr(self.backbone, name)
-            self.neck = fpn_mod.PANetFPN([128, 256, 512], in_pyramid_levels=cfg['backbone_feature_pyramid_levels'],
-                                         out_pyramid_levels=cfg['neck_feature_pyramid_levels'],
-                                         features_num=cfg['neck_config']['features_num'],
-                                         panet_buttomup=(neck == 'panet-fpn'))
-            self.anchors = anc_mod.Anchors(pyramid_levels=cfg['neck_feature_pyramid_levels'], **cfg['anchors_config'])
+            if bifpn:                                                       # ksevendet.py:64-86
+                self.neck = bifpn_mod.BiFPN([128, 256, 512], in_pyramid_levels=cfg['backbone_feature_pyramid_levels'],
+                                            neck_pyramid_levels=cfg['neck_feature_pyramid_levels'],
+                                            out_pyramid_levels=head_levels, features_num=cfg['neck_config']['features_num'],
+                                            repeats=cfg['neck_config']['bifpn_repeats'],
+                                            attention=cfg['neck_config']['bifpn_attention'])
+            else:
+                self.neck = fpn_mod.PANetFPN([128, 256, 512], in_pyramid_levels=cfg['backbone_feature_pyramid_levels'],
+                                             out_pyramid_levels=cfg['neck_feature_pyramid_levels'],
+                                             features_num=cfg['neck_config']['features_num'],
+                                             panet_buttomup=(neck == 'panet-fpn'))
+            self.anchors = anc_mod.Anchors(pyramid_levels=head_levels, **cfg['anchors_config'])
             na = len(self.anchors.ratios) * len(self.anchors.scales)
             self.regressor = head_mod.Regressor(cfg['neck_config']['features_num'], num_anchors=na,
-                                                num_pyramid_levels=5, **cfg['head_config'])
+                                                num_pyramid_levels=len(head_levels), **cfg['head_config'])
             self.classifier = head_mod.Classifier(cfg['neck_config']['features_num'], num_anchors=na,
-                                                  num_classes=num_classes, num_pyramid_levels=5, **cfg['head_config'])
+                                                  num_classes=num_classes, num_pyramid_levels=len(head_levels), **cfg['head_config'])
             self.focalLoss = ref_losses.FocalLoss()
 
         def heads(self, img):                                               # ksevendet.py:203-231
@@ -534,7 +554,8 @@ def gen_e2e_kseven(neck, H, W, B, num_classes, tag, gain, train_bn_heads=False):
     (cl.mean() + rl.mean()).backward()
     grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters()}
     d = dict(cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(), hw=np.array([H, W]), batch=np.array(B),
-             num_classes=np.array(num_classes), gain=np.array(gain), neck=np.array(neck),
+             num_classes=np.array(num_classes), gain=np.array(gain), neck=np.array(neck), head_levels=np.array(head_levels),
+             repeats=np.array(cfg['neck_config'].get('bifpn_repeats', 0)),
              train_bn_heads=np.array(train_bn_heads))
     idx = np.arange(0, cls.shape[1], 29)
     d['head_idx'], d['cls_rows'], d['reg_rows'] = idx, cls.numpy()[:, idx, :], reg.numpy()[:, idx, :]
@@ -737,6 +758,10 @@ if __name__ == '__main__':
         gen_e2e_kseven('fpn', 128, 160, 2, 12, 'kseven_r18_fpn_128x160', 0.87)
         gen_e2e_kseven('panet-fpn', 128, 128, 2, 12, 'kseven_r18_panet_128', 0.87)
         gen_e2e_kseven('fpn', 128, 128, 4, 12, 'kseven_r18_headbn_128', 0.87, train_bn_heads=True)
+    if 'kseven_bifpn' in which:
+        # (gains: the BiFPN's un-normalised node sums amplify; 0.87 gives logits in the hundreds, <= 0.7 leaves the prior)
+        gen_e2e_kseven('bifpn', 128, 256, 2, 12, 'kseven_r18_bifpn_128x256', 0.8)
+        gen_e2e_kseven('bifpn2', 128, 128, 2, 12, 'kseven_r18_bifpn2_128', 0.76)
     if 'trainbn' in which:
         gen_e2e_trainbn(18, 128, 128, 4, 12, 'r18_trainbn_128', 0.87)
     if 'syncbn' in which:
