@@ -25,6 +25,10 @@ from .ops_conv import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvLaunch, dgrad_proble
                        out_hw, pick_split_rows)
 
 
+GUARD_BYTES = 4096 if os.environ.get('MI355_GUARD', '0') == '1' else 0
+GUARD_PATTERN = 0xA5
+
+
 def _ceil8(v):
     return (v + 7) // 8 * 8
 
@@ -211,9 +215,44 @@ class RetinaPlan(object):
 
     # ------------------------------------------------------------------ bookkeeping
     def new(self, shape, dtype=None, zero=False):
+        if GUARD_BYTES:
+            return self._new_guarded(shape, dtype or self.adt, zero)
         t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype or self.adt, device=self.dev)
         self.bufs.append(t)
         return t
+
+    # MI355_GUARD=1 (a debugging mode, tests/test_gpu_guards.py): every plan buffer sits between two 4 KiB zones filled
+    # with a byte pattern; `check_guards()` names the buffers a launch wrote past.  An out-of-bounds store of a
+    # hand-written kernel otherwise lands in a neighbouring block of torch's caching allocator and shows up as a wrong
+    # number somewhere else, or as a memory fault only when the buffer happens to end a segment.
+    def _new_guarded(self, shape, dtype, zero):
+        import traceback
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        raw = torch.full((nbytes + 2 * GUARD_BYTES,), GUARD_PATTERN, dtype=torch.uint8, device=self.dev)
+        body = raw[GUARD_BYTES:GUARD_BYTES + nbytes]
+        if zero:
+            body.zero_()
+        t = body.view(dtype).view(shape)
+        fr = [f for f in traceback.extract_stack(limit=6)[:-2] if 'new' != f.name]
+        where = ' < '.join('%s:%d' % (f.name, f.lineno) for f in reversed(fr[-3:]))
+        self.__dict__.setdefault('_guards', []).append((raw, nbytes, where, shape, dtype))
+        self.bufs.append(t)
+        return t
+
+    def check_guards(self):
+        """[(where, shape, dtype, side, first bad byte offset)] of the guard zones that no longer hold the pattern."""
+        bad = []
+        for raw, nbytes, where, shape, dtype in self.__dict__.get('_guards', []):
+            for side, zone in (('before', raw[:GUARD_BYTES]), ('after', raw[GUARD_BYTES + nbytes:])):
+                ne = (zone != GUARD_PATTERN).nonzero()
+                if ne.numel():
+                    off = int(ne[0].item()) - (GUARD_BYTES if side == 'before' else 0)
+                    bad.append((where, shape, str(dtype), side, off, int(ne.numel())))
+        return bad
 
     def _ptr_signature(self):
         # (cached tensor objects: walking the module tree costs ~1 ms per step; `.data` re-homing, `.to()` and
@@ -443,8 +482,11 @@ class RetinaPlan(object):
         self.grad_offsets = offs
         self.grad_numel = total
         self.grad_numel_padded = (total + 3) // 4 * 4
-        self.grad_arenas = [torch.zeros(self.grad_numel_padded, dtype=torch.float32, device=self.dev)
-                            for _ in range(2)]
+        if GUARD_BYTES:
+            self.grad_arenas = [self._new_guarded((self.grad_numel_padded,), torch.float32, True) for _ in range(2)]
+        else:
+            self.grad_arenas = [torch.zeros(self.grad_numel_padded, dtype=torch.float32, device=self.dev)
+                                for _ in range(2)]
         self.active = 0
         shadow = sum(s.K * s.T * s.Cpad + (s.C * s.T * s.Kpad if s.need_dgrad else 0) for s in self.specs)
         self.shadow = self.new((shadow + 64,), self.adt, zero=True)
