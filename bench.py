@@ -528,11 +528,15 @@ def main():
                            'algorithmic_gflop_per_image': round(train_f / B / 1e9, 2),
                            'conv_ms_per_step': round(conv_ms, 3)}
         if args.sync_bn:
-            bn_ms, nbn = time_conv_kernels(plan, 5, prefix=('mi355_bn_nhwc', 'py:bn_allreduce'))
+            bn_ms, nbn = time_conv_kernels(plan, 5, prefix=('mi355_bn_nhwc', 'py:bn_allreduce', 'mi355_rccl_'))
             nlayers = len(plan.bn_saved)
             out['sync_bn'] = {'bn_layers': nlayers, 'bn_launches_per_step': nbn, 'bn_ms_per_step': round(bn_ms, 3),
                               'bn_us_per_layer_and_direction': round(1e3 * bn_ms / max(2 * nlayers, 1), 2),
-                              'collectives_per_step': sum(1 for st in plan.fwd_steps + plan.bwd_steps if st[2].startswith('py:')),
+                              'collectives_per_step': sum(1 for st in plan.fwd_steps + plan.bwd_steps
+                                                          if st[2].startswith(('py:', 'mi355_rccl_'))),
+                              'collectives_issued_by': ('the launch-plan runner (mi355_rccl_allreduce_sum_f32 table steps)'
+                                                        if any(st[2].startswith('mi355_rccl_') for st in plan.fwd_steps)
+                                                        else 'torch.distributed host steps'),
                               'group': '%s, world size %d' % (dist.get_backend() if dist.is_initialized() else None, world)}
     if args.arch.startswith('ksevendet') or args.sync_bn:   # (supplementary lines: training step + roofline only)
         args.no_infer = args.no_cpu_baseline = True

@@ -57,6 +57,13 @@ int mi355_plan_run(const Mi355PlanStep* steps, int begin, int end, void* main_st
 /* Order `main_stream` behind the side streams' work so far (side2 -> side -> main) and clear the dirty flags;
  * fold_only != 0: only side2 -> side (before something on `side` that needs every weight gradient). */
 int mi355_plan_join(void* main_stream, void* side_stream, void* side2_stream, Mi355PlanState* state, int fold_only);
+/* In-place sum all-reduce of `n` floats over an RCCL communicator, issued on `stream` from the runner itself: the
+ * cross-replica exchange of the BatchNorm statistics ([sum | square-sum] forward, [sum g | sum g*zhat] backward,
+ * utils/sync_batchnorm/batchnorm.py:105-126: ReduceAddCoalesced + Broadcast) as a TABLE step between the statistics and
+ * the normalisation launches of a layer - no host round trip per layer and direction, and part of a hipGraph capture.
+ * `comm` is the ncclComm_t of the process group (torch: ProcessGroupNCCL._comm_ptr()); ncclAllReduce is resolved from
+ * the RCCL library already loaded in the process.  MI355_EINVAL when no RCCL is loaded. */
+int mi355_rccl_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);
 /* Zero `n` device ranges in ONE launch: table[i] = {pointer, bytes} (4-byte granular), device resident; `blocks`
  * workgroups stride over each range (size it for the largest: about one per 64 KiB, at most 1024). */
 int mi355_zero_ranges(const void* table, int n, int blocks, void* stream);

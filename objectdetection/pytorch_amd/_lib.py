@@ -46,10 +46,35 @@ def lib():
     return _lib
 
 
+# MI355_TRACE=<file>: fault attribution (tools/find_fault.py).  Every launch is announced in the file (flushed to disk)
+# BEFORE it is enqueued and the device is synchronised behind it, so that when the runtime aborts the process on a GPU
+# memory fault the last line names the launch that faulted.  Plans replay through the Python loop in this mode.
+TRACE_PATH = os.environ.get('MI355_TRACE') or None
+_trace_fh = None
+
+
+def trace_begin(tag):
+    global _trace_fh
+    if _trace_fh is None:
+        _trace_fh = open(TRACE_PATH, 'a')
+    _trace_fh.write(tag + '\n')
+    _trace_fh.flush()
+    os.fsync(_trace_fh.fileno())
+
+
+def trace_end():
+    import torch
+    torch.cuda.synchronize()
+
+
 def call(name, *args):
     """Call `name(*args)`; raise Mi355Error with the library's message on a non-zero code."""
     fn = getattr(lib(), name)
+    if TRACE_PATH:
+        trace_begin('call %s' % name)
     rc = fn(*args)
+    if TRACE_PATH and rc == 0:
+        trace_end()
     if rc != 0:
         msg = lib().mi355_last_error()
         raise Mi355Error('%s failed (%d): %s' % (name, rc, msg.decode() if msg else '?'))

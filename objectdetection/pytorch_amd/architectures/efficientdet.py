@@ -201,9 +201,12 @@ class EfficientDet(nn.Module):
         if not img.is_cuda:
             raise RuntimeError('mi355det EfficientDet: input on %s; the HIP path needs a ROCm GPU tensor '
                                '(there is no CPU fallback)' % img.device)
-        for m in self.modules():
-            if isinstance(m, nn.BatchNorm2d) and m.training:
-                raise RuntimeError('train-mode BatchNorm is not on the frozen-BN hot path: call freeze_bn()')
+        # frozen BN (train.py:282-286, the reference loop) folds into the convs; layers left in train mode (or made
+        # SynchronizedBatchNorm2d by utils.utils.replace_w_sync_bn) get batch-statistics passes in the plan
+        if getattr(self, '_bn_list', None) is None:
+            self._bn_list = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        bn_sig = tuple(m.training for m in self._bn_list)
+        bn_sig = bn_sig if any(bn_sig) else ()
         # drop-connect runs while the MBConv blocks are in train mode (efficientnet.py:109-113 `training=self.training`)
         gp = self.backbone_net.model._global_params
         dc = bool(getattr(gp, 'drop_connect_rate', None)) and any(b.training for b in self.backbone_net.model._blocks)
@@ -211,6 +214,8 @@ class EfficientDet(nn.Module):
         from .. import engine
         if engine.precision_of(self) != 'bf16':          # `model.precision = 'fp32'`: the fp32-accurate plan
             key = key + (engine.precision_of(self),)
+        if bn_sig:
+            key = key + (bn_sig,)
         from .retinanet import _cached_plan
 
         def build():

@@ -59,6 +59,7 @@ struct WLaunch {
     // grouped launches: chunks sorted by length (longest first), so that the short chunks of the small
     // pyramid levels fill the tail of the launch instead of opening a second round of full-length blocks
     int ub;                                     // XCD-local unit size in logical blocks (1: none)
+    int xs;                                     // row-of-taps kernels: blocks of one XCD take consecutive logical ids
     int nsorted;                                // 0: chunk -> problem by chunk_begin (single problem)
     unsigned char ch_prob[MAX_SORTED];
     int ch_mbegin[MAX_SORTED];
@@ -387,7 +388,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
     constexpr int NJ = KH ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int b = blockIdx.x;
+    // The (kernel row, k tile, c tile) blocks of a pixel chunk read the same dy / activation rows.  Consecutive
+    // blockIdx go round-robin over the 8 XCDs (one L2 each): in plain order every chunk's rows are fetched into all
+    // eight L2s (PMC: 425 MB read per head-tower launch for 90 MB of operands).  L.xs: XCD x takes a contiguous range
+    // of logical ids instead (xcd_swizzle), i.e. whole chunks; set when every block of the launch is resident at once,
+    // so that the longest-first chunk order cannot unbalance the XCDs (MI355_WG_XCD=0: plain order).
+    int b = L.xs ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int c_tile = b % L.c_tiles;  b /= L.c_tiles;
     const int k_tile = b % L.k_tiles;  b /= L.k_tiles;
     const int kr = b % 3;              b /= 3;          // kernel row of this block
@@ -662,7 +668,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: scalar branches on the wave index
-    int b = blockIdx.x;
+    // The (kernel row, k tile, c tile) blocks of a pixel chunk read the same dy / activation rows.  Consecutive
+    // blockIdx go round-robin over the 8 XCDs (one L2 each): in plain order every chunk's rows are fetched into all
+    // eight L2s (PMC: 425 MB read per head-tower launch for 90 MB of operands).  L.xs: XCD x takes a contiguous range
+    // of logical ids instead (xcd_swizzle), i.e. whole chunks; set when every block of the launch is resident at once,
+    // so that the longest-first chunk order cannot unbalance the XCDs (MI355_WG_XCD=0: plain order).
+    int b = L.xs ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int c_tile = b % L.c_tiles;  b /= L.c_tiles;
     const int k_tile = b % L.k_tiles;  b /= L.k_tiles;
     const int kr = b % 3;              b /= 3;          // kernel row of this block
@@ -1159,6 +1170,11 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
         for (int i = 0; i < 2; ++i)
             if (cand[i] > 1 && grid % cand[i] == 0 && (grid / cand[i]) % 8 == 0) { L.ub = cand[i]; break; }
     }
+    static const int xcd_mode = [] {
+        const char* e = getenv("MI355_WG_XCD");
+        return e ? atoi(e) : 1;
+    }();
+    L.xs = (xcd_mode && row3 && grid <= (row3x ? 256 : 512)) ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));

@@ -156,6 +156,29 @@ extern "C" int mi355_plan_join(void* main_stream, void* side_stream, void* side2
     return MI355_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- RCCL step
+// ncclAllReduce(sendbuff, recvbuff, count, datatype, op, comm, stream): resolved once from the RCCL the process already
+// holds (torch's bundled librccl.so: the library the communicator belongs to), never linked against.
+#include <dlfcn.h>
+extern "C" int mi355_rccl_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream) {
+    typedef int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static AllReduce fn = [] {
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        if (!sym) {
+            void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+            if (h) sym = dlsym(h, "ncclAllReduce");
+        }
+        return (AllReduce)sym;
+    }();
+    MI355_REQUIRE(comm && buf && n > 0, "rccl_allreduce: bad args");
+    MI355_REQUIRE(fn != nullptr, "rccl_allreduce: no RCCL library is loaded in this process (ncclAllReduce not found)");
+    constexpr int kFloat32 = 7, kSum = 0;                         // ncclFloat32, ncclSum (rccl.h)
+    const int rc = fn(buf, buf, (size_t)n, kFloat32, kSum, comm, (hipStream_t)stream);
+    if (rc != 0) return fail(MI355_ELAUNCH, "rccl_allreduce: ncclAllReduce returned %d", rc);
+    return MI355_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- zero ranges
 struct ZeroRange { void* p; int64_t bytes; };
 

@@ -149,7 +149,7 @@ F32_TWINS = {'mi355_conv_gather': 'mi355_conv_gather_f32', 'mi355_conv_wgrad_sla
              'mi355_drop_connect': 'mi355_drop_connect_f32', 'mi355_drop_connect_bwd': 'mi355_drop_connect_bwd_f32', 'mi355_upsample_bwd_axpy': 'mi355_upsample_bwd_axpy_f32',
              'mi355_maxpool_same_fwd': 'mi355_maxpool_same_fwd_f32', 'mi355_maxpool_same_bwd': 'mi355_maxpool_same_bwd_f32'}
 # entry points that never see an activation tensor (fp32 vectors / parameter tables): the same in both modes
-F32_NEUTRAL = ('mi355_se_fc', 'mi355_se_fc_bwd', 'mi355_se_slabs', 'mi355_fusion_weights', 'mi355_dw_prep', 'mi355_dw_param',
+F32_NEUTRAL = ('mi355_rccl_', 'mi355_se_fc', 'mi355_se_fc_bwd', 'mi355_se_slabs', 'mi355_fusion_weights', 'mi355_dw_prep', 'mi355_dw_param',
                'mi355_prep_weights', 'mi355_param_grads', 'mi355_bn_nhwc', 'mi355_focal', 'mi355_stream')
 
 
@@ -320,7 +320,7 @@ class RetinaPlan(object):
         (MI355_SIDE_STREAM=1) the weight-gradient launches (and the box head) go to a second HIP stream, forked behind
         everything issued so far: a wgrad and the data gradient of the same layer only share inputs, so they run
         concurrently and fill each other's ramp-up / tail; `join_side()` is the fence in front of the consumers of dW."""
-        if os.environ.get('MI355_PLAN_PY') == '1':
+        if os.environ.get('MI355_PLAN_PY') == '1' or _lib.TRACE_PATH:
             return self._run_py(steps, stream, begin, end)
         arr, n, hosts, _ = self._compiled(steps)
         end = n if end is None else end
@@ -351,15 +351,20 @@ class RetinaPlan(object):
         s = c_vp(stream)
         side = c_vp(self._side_stream().cuda_stream) if self._side_active() else None
         fork = self.lib.mi355_stream_fork
-        for fn, args, name in steps[begin:end]:
+        which = {id(self.prep_steps): 'prep', id(self.fwd_steps): 'fwd', id(self.bwd_steps): 'bwd'}.get(id(steps), 'steps')
+        for i, (fn, args, name) in enumerate(steps[begin:end]):
             if name.startswith('py:'):
                 fn(stream)
                 continue
+            if _lib.TRACE_PATH:
+                _lib.trace_begin('%s[%d] %s' % (which, begin + i, name))
             if side is not None and (name in self.SIDE_STEPS or id(args) in self._side_ids):
                 rc = fork(s, side) or fn(*args, side)
                 self._pstate.side_dirty = 1
             else:
                 rc = fn(*args, s)
+            if _lib.TRACE_PATH and not rc:
+                _lib.trace_end()
             if rc:
                 raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, self.lib.mi355_last_error().decode()))
 
@@ -751,6 +756,35 @@ class RetinaPlan(object):
             dist.all_reduce(buf, group=group)       # SUM of [sum | square-sum] (batchnorm.py:118: ReduceAddCoalesced)
         return run
 
+    def _rccl_comm(self, group):
+        """ncclComm_t of `group` on this device when its backend is RCCL (torch: ProcessGroupNCCL._comm_ptr()), else
+        None.  The communicator is made by the first collective on the device: one 1-element all-reduce at build time."""
+        cache = self.__dict__.setdefault('_rccl_comms', {})
+        key = id(group)
+        if key not in cache:
+            comm = None
+            try:
+                import torch.distributed as dist
+                if os.environ.get('MI355_BN_NATIVE_RCCL', '1') != '0' and dist.get_backend(group) == 'nccl':
+                    dist.all_reduce(torch.zeros(1, device=self.dev), group=group)
+                    torch.cuda.synchronize(self.dev)
+                    pg = group if group is not None else dist.distributed_c10d._get_default_group()
+                    comm = int(pg._get_backend(self.dev)._comm_ptr()) or None
+            except Exception:                                   # (gloo, an older torch without _comm_ptr: host steps)
+                comm = None
+            cache[key] = comm
+        return cache[key]
+
+    def _bn_exchange_step(self, lst, buf, group):
+        """The cross-replica sum of a layer's statistics vector inside a launch list: a TABLE step on the launch stream
+        when the group is an RCCL one (mi355_rccl_allreduce_sum_f32: no return to Python per layer and direction, and
+        capturable), else a host step that calls torch.distributed (gloo in the CPU-side tests)."""
+        comm = self._rccl_comm(group)
+        if comm:
+            self._step(lst, 'mi355_rccl_allreduce_sum_f32', c_vp(comm), ptr(buf), c_i64(buf.numel()))
+        else:
+            self._pystep(lst, self._bn_allreduce(buf, group), 'py:bn_allreduce')
+
     def bn_fwd(self, spec, bn, z, act, addend, tag=None):
         """Batch statistics of z [N,P,Q,C] -> layer state -> y = act(z*scale + shift (+ addend)).  Records what the
         backward needs under `tag` (default: the spec) in self.bn_saved."""
@@ -769,7 +803,7 @@ class RetinaPlan(object):
         self._step(lst, 'mi355_bn_nhwc_stats', ptr(z), c_vp(0), c_vp(0), f32, c_i64(M), c_int(C), c_int(0), ptr(partials))
         self._step(lst, 'mi355_bn_nhwc_reduce', ptr(partials), c_int(nblk.value), c_int(C), ptr(sums), c_vp(0), c_vp(0))
         if sync and group_exchange(world):
-            self._pystep(lst, self._bn_allreduce(sums, group), 'py:bn_allreduce')
+            self._bn_exchange_step(lst, sums, group)
         track = bn.track_running_stats and bn.running_mean is not None
         plain = type(bn) is torch.nn.BatchNorm2d            # nn.BatchNorm2d.forward counts batches; the sync class does not
         self._step(lst, 'mi355_bn_nhwc_finalize', ptr(sums), c_f32(float(M) * world), c_int(C), c_f32(bn.eps),
@@ -794,7 +828,7 @@ class RetinaPlan(object):
         self._step(lst, 'mi355_bn_nhwc_reduce', ptr(partials), c_int(partials.shape[0]), c_int(C), ptr(gsums),
                    ptr(self.grad_view(bn.weight, arena)), ptr(self.grad_view(bn.bias, arena)))
         if sync and group_exchange(world):
-            self._pystep(lst, self._bn_allreduce(gsums, group), 'py:bn_allreduce')
+            self._bn_exchange_step(lst, gsums, group)
         dz = self.new(tuple(g.shape))
         self._step(lst, 'mi355_bn_nhwc_bwd_apply', ptr(g), ptr(z), ptr(state), ptr(gsums), c_f32(1.0 / (float(M) * world)),
                    f32, c_i64(M), c_int(C), ptr(dz))

@@ -35,6 +35,10 @@ class DwSpec(object):
         self.k = conv.weight.shape[2]
         self.stride = conv.stride[0]
         self.T = self.k * self.k
+        # a BatchNorm left in train mode (or made SynchronizedBatchNorm2d) is not folded: the conv stores the raw z and
+        # the plan runs the statistics passes of engine.RetinaPlan.bn_fwd / bn_bwd behind it
+        self.bn_train = bn is not None and bn.training
+        self.folded_bn = bn if (bn is not None and not self.bn_train) else None
         self.w_t = self.scale = self.shift = self.G_t = self.colsum = None
         self.nslabs, self.slabs = 0, None       # partial-sum rows of the weight gradient (mi355_dwconv_wgrad_slabs)
 
@@ -140,7 +144,7 @@ class EffDetPlan(RetinaPlan):
     def _alloc_params(self):
         super(EffDetPlan, self)._alloc_params()
         n_w = sum(s.T * s.C for s in self.dw_specs)
-        n_bn = sum(2 * s.C for s in self.dw_specs if s.bn is not None)
+        n_bn = sum(2 * s.C for s in self.dw_specs if s.folded_bn is not None)
         n_g = sum(s.T * s.C + s.C for s in self.dw_specs)
         self.dw_wbuf = self.new((n_w + n_bn + 8,), torch.float32)
         self.dw_scratch = self.new((n_g + 8,), torch.float32, zero=True)
@@ -148,7 +152,7 @@ class EffDetPlan(RetinaPlan):
         for s in self.dw_specs:
             s.w_t = self.dw_wbuf[wo:wo + s.T * s.C]
             wo += s.T * s.C
-            if s.bn is not None:
+            if s.folded_bn is not None:
                 s.scale = self.dw_wbuf[wo:wo + s.C]
                 s.shift = self.dw_wbuf[wo + s.C:wo + 2 * s.C]
                 wo += 2 * s.C
@@ -163,7 +167,7 @@ class EffDetPlan(RetinaPlan):
         rows = []
         for s in self.dw_specs:
             assert s.conv.weight.is_contiguous()
-            bn = s.bn
+            bn = s.folded_bn
 
             def dp(t):
                 return 0 if t is None else t.data_ptr()
@@ -233,6 +237,12 @@ class EffDetPlan(RetinaPlan):
         # bf16 exactly like a materialised swish(z)): no elementwise pass, no second copy of the activation
         xs, insw = x, int(bool(x_swish))
         self._last_se_pool = None
+        raw = out
+        if spec.bn_train:
+            # raw depthwise output -> batch statistics -> normalised pre-activation (swish stays on the consumer's load);
+            # the fused squeeze-excite forms pool / rebuild the BN OUTPUT, which this launch does not have yet
+            assert emit_fwd, spec.name
+            se_pool = False
         if se_pool and emit_fwd and self.prec != 'fp32' and os.environ.get('MI355_EFF_FUSE_SEPOOL', '1') != '0':
             ns = ctypes.c_int()
             _lib.call('mi355_dwconv_fwd_sepool_slabs', c_int(H), c_int(W), c_int(spec.k), c_int(spec.stride), c_int(P),
@@ -246,6 +256,9 @@ class EffDetPlan(RetinaPlan):
         if emit_fwd:
             self._step(self.fwd_steps, 'mi355_dwconv_fwd', ptr(xs), c_int(insw), ptr(spec.w_t), ptr(spec.shift),
                        ptr(out), *geo)
+        if spec.bn_train:
+            out = self.bn_fwd(spec, spec.bn, raw, ACT_NONE, None)
+        has_beta = int(spec.folded_bn is not None)       # (train-mode BN: d beta / d gamma come from bn_bwd's sums)
 
         # bf16 plans: bit-reproducible weight gradient, every launch of the layer (the pyramid levels of a shared head
         # conv) stores its own partial rows of the layer's slab workspace; fp32 plans: the generic atomic kernel
@@ -266,6 +279,8 @@ class EffDetPlan(RetinaPlan):
             if not self.has_grad(out):
                 return
             dy = self.grad(out)
+            if spec.bn_train:
+                dy = self.bn_bwd(spec, dy)
             pend = self._se_apply_in_dgrad.get(id(out)) if fuse_apply else None
             if pend is not None:                            # data gradient first: it also stores dy for the weight gradient
                 gu, gate, gpool = pend
@@ -280,11 +295,11 @@ class EffDetPlan(RetinaPlan):
                     spec.slabs = self.new((spec.nslabs, row), torch.float32, zero=True)
                 self._step(self.bwd_steps, 'mi355_dwconv_wgrad_slabs', ptr(xs), c_int(insw), ptr(dy),
                            c_vp(spec.slabs.data_ptr() + slab_base * row * 4),
-                           c_int(int(spec.bn is not None)), *geo)
+                           c_int(has_beta), *geo)
             else:
                 self._dw_atomic = True                      # dw_scratch is accumulated into: cleared every step
                 self._step(self.bwd_steps, 'mi355_dwconv_wgrad', ptr(xs), c_int(insw), ptr(dy), ptr(spec.G_t),
-                           ptr(spec.colsum if spec.bn is not None else None), *geo)
+                           ptr(spec.colsum if has_beta else None), *geo)
             if pend is None:
                 dx = self.grad(x)
                 acc = not self.first_write(x)
@@ -762,7 +777,7 @@ class EffDetPlan(RetinaPlan):
         if tab is None:
             rows = []
             for s in self.dw_specs:
-                bn = s.bn
+                bn = s.folded_bn
 
                 def dp(t):
                     return 0 if t is None else t.data_ptr()

@@ -311,6 +311,8 @@ class Trainer(object):
                    c_f32(self.eps), c_f32(self.wd), ptr(self.state), c_int(1), ptr(skip), c_int(nskip), s)
 
     def _call(self, name, *args):
+        if _lib.TRACE_PATH:
+            return _lib.call(name, *args)
         rc = getattr(self.lib, name)(*args)
         if rc:
             raise _lib.Mi355Error('%s failed (%d): %s' % (name, rc, self.lib.mi355_last_error().decode()))

@@ -164,6 +164,116 @@ def test_trainbn_plan_vs_reference_golden(golden_dir, precision):
     assert torch.isfinite(s).all()
 
 
+def _effdet_trainbn_model(dev, g, precision):
+    from objectdetection.pytorch_amd.architectures import efficientdet
+    model = efficientdet.build_efficientdet('efficientdet-d%d' % int(g['coef']), num_classes=int(g['num_classes']))
+    model.precision = precision
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=float(g['gain']), head_std=float(g['head_std']))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    model.train()                                             # every BatchNorm2d in train mode (no freeze_bn)
+    synth.disable_drop_connect(model)
+    return model
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_effdet_trainbn_plan_vs_reference_golden(golden_dir, precision):
+    """EfficientDet-D0 with EVERY BatchNorm in train mode (VERDICT r02 missing #2: `replace_w_sync_bn(efficientdet)`
+    could not train): stem, the expand / depthwise / project BNs of the MBConv blocks, the BiFPN's down-channel and
+    separable convs, the heads' per-level BNs.  Golden made by the reference itself in train mode
+    (tools/make_golden.py:gen_effdet_trainbn): losses, running statistics after one forward (momentum 0.01,
+    unbiased variance), gradients against the reference's own fp32-vs-fp64 noise."""
+    g = np.load(os.path.join(golden_dir, 'e2e_effdet_d0_trainbn_128x256.npz'))
+    dev = torch.device('cuda', 0)
+    (H, W), B, nc = g['hw'], int(g['batch']), int(g['num_classes'])
+    model = _effdet_trainbn_model(dev, g, precision)
+    img = torch.from_numpy(synth.synth_images(B, int(H), int(W), seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(B, int(H), int(W), 6, 8, nc, seed=2)).to(dev)
+    cl, rl = model(img, ann)
+    ltol = 1e-4 if precision == 'fp32' else 3e-2
+    np.testing.assert_allclose(cl.item(), g['cls_loss'].item(), rtol=ltol)
+    np.testing.assert_allclose(rl.item(), g['reg_loss'].item(), rtol=ltol)
+    sd = model.state_dict()
+    nrun = 0
+    for key in g.files:
+        if key.startswith('running/'):
+            name = key[8:]
+            got = sd[name].cpu().numpy()
+            nrun += 1
+            if name.endswith('num_batches_tracked'):
+                assert int(got) == int(g[key]) == 1
+            else:
+                np.testing.assert_allclose(got, g[key], rtol=1e-4 if precision == 'fp32' else 3e-2,
+                                           atol=1e-6 if precision == 'fp32' else 3e-3, err_msg=name)
+    assert nrun == 24
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = dict((k, p.grad) for k, p in model.named_parameters())
+    gn = np.sqrt(sum(float((v.double() ** 2).sum()) for v in grads.values() if v is not None))
+    # (bf16: batch statistics over as few as 6 elements per channel - the P7 level of the per-level head BNs at this size -
+    #  amplify the storage rounding of z: measured 14 % on the global norm, against 1e-3 in the fp32 mode)
+    np.testing.assert_allclose(gn, float(g['grad_global_norm']), rtol=1e-3 if precision == 'fp32' else 2.5e-1)
+    checked = 0
+    for key in g.files:
+        if key.startswith('grad/') and key.endswith('/val'):
+            name = key[5:-4]
+            sel = torch.from_numpy(g['grad/%s/idx' % name]).to(dev)
+            got = grads[name].reshape(-1)[sel].cpu().numpy().astype(np.float64)
+            ref, ref64 = g[key].astype(np.float64), g['grad64/%s/val' % name].astype(np.float64)
+            if np.linalg.norm(ref64) < 1e-9 * gn:           # a conv bias in front of a BN: exactly 0 in exact arithmetic
+                assert np.linalg.norm(got) < 1e-4 * gn, name
+                continue
+            noise = float(np.linalg.norm(ref - ref64) / np.linalg.norm(ref64))
+            e32 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            print('  %-62s reference fp32-vs-fp64 %.2e | ours vs golden %.2e' % (name, noise, e32))
+            checked += 1
+            if precision == 'fp32':
+                assert e32 <= max(1e-3, 3.0 * noise), (name, e32, noise)
+            else:
+                cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+                print('      cosine %.4f' % cos)
+                assert cos > 0.8, (name, cos)
+    assert checked >= 20
+    # a second forward moves the running statistics again; eval afterwards folds them (a different plan)
+    model(img, ann)
+    assert int(model.backbone_net.model._bn0.num_batches_tracked) == 2
+    model.eval()
+    s, c, b = model(img[:1], return_loss=False)
+    assert torch.isfinite(s).all()
+
+
+def test_effdet_replace_w_sync_bn_trains_on_one_replica():
+    """utils/utils.py:140-168 on EfficientDet: every BN the reference's `dir(m)` walk reaches becomes
+    SynchronizedBatchNorm2d; on one replica the plan runs the train-mode passes (batchnorm.py:65-69) and a Trainer step
+    updates gamma / beta and the running statistics."""
+    from objectdetection.pytorch_amd.architectures import efficientdet
+    from objectdetection.pytorch_amd.trainer import Trainer
+    from objectdetection.pytorch_amd.utils.sync_batchnorm import SynchronizedBatchNorm2d
+    from objectdetection.pytorch_amd.utils.utils import replace_w_sync_bn
+    dev = torch.device('cuda', 0)
+    model = efficientdet.build_efficientdet('efficientdet-d0', num_classes=8)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=1.0, head_std=0.05)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    replace_w_sync_bn(model)
+    assert type(model.backbone_net.model._bn0) is SynchronizedBatchNorm2d
+    assert type(model.backbone_net.model._blocks[3]._bn1) is SynchronizedBatchNorm2d
+    model = model.to(dev)
+    model.train()
+    synth.disable_drop_connect(model)
+    img = torch.from_numpy(synth.synth_images(2, 128, 128, seed=1)).to(dev)
+    ann = torch.from_numpy(synth.synth_annotations(2, 128, 128, 6, 8, 8, seed=2)).to(dev)
+    bn = model.backbone_net.model._blocks[3]._bn1
+    g0, rm0 = bn.weight.detach().clone(), bn.running_mean.clone()
+    tr = Trainer(model)
+    l1 = tr.step(img, ann)
+    l2 = tr.step(img, ann)
+    torch.cuda.synchronize()
+    assert torch.isfinite(l1).all() and torch.isfinite(l2).all() and tr.step_count == 2
+    assert not torch.equal(bn.weight.detach(), g0) and not torch.equal(bn.running_mean, rm0)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))

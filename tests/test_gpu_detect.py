@@ -124,11 +124,23 @@ def test_decode_clip_golden(golden_dir, dev):
     from objectdetection.pytorch_amd.architectures.utils import BBoxTransform, ClipBoxes
     g = _g(golden_dir, 'decode.npz')
     boxes = BBoxTransform()(torch.from_numpy(g['anchors']).to(dev), torch.from_numpy(g['reg']).to(dev))
-    np.testing.assert_allclose(boxes.cpu().numpy(), g['boxes'], rtol=RTOL, atol=1e-3)
+
+    def check(got, ref, raw):
+        # A corner is centre -/+ half the size (utils.py:46-51): its rounding error scales with those OPERANDS, not with
+        # the corner itself (x1 = 2.5 may come from 400.0 - 397.5).  Bound: 1e-4 relative on the corner (north star) plus
+        # 4 fp32 ulps (4.8e-7) of the box's operand scale max(|corner|, width, height) of the UNCLIPPED reference box -
+        # libm expf vs the device's exp (<= 2 ulp on the size) and fused vs separate multiply-add on the centre (measured: 1.41).
+        scale = np.maximum(np.abs(raw).max(-1), np.maximum(raw[..., 2] - raw[..., 0], raw[..., 3] - raw[..., 1]))[..., None]
+        err = np.abs(got.astype(np.float64) - ref)
+        bound = RTOL * np.abs(ref) + 4 * 2.0 ** -23 * scale
+        assert (err <= bound).all(), (float((err / bound).max()), float(err.max()))
+        return float((err / (2.0 ** -23 * scale)).max())
+    u1 = check(boxes.cpu().numpy(), g['boxes'], g['boxes'])
     h, w = int(g['hw'][0]), int(g['hw'][1])
     ret = ClipBoxes()(boxes, torch.zeros(2, 3, h, w, device=dev))
     assert ret.data_ptr() == boxes.data_ptr()              # mutates and returns (utils.py:61-71)
-    np.testing.assert_allclose(boxes.cpu().numpy(), g['clipped'], rtol=RTOL, atol=1e-3)
+    u2 = check(boxes.cpu().numpy(), g['clipped'], g['boxes'])
+    print('decode: worst error %.2f / %.2f ulps of the operand scale' % (u1, u2))
 
 
 def _rand_boxes(rng, n, span=200.0, size=60.0):

@@ -83,6 +83,7 @@ def test_effdet_vs_reference_golden(golden_dir, tag):
             cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
             ratio = float(np.linalg.norm(got) / (np.linalg.norm(ref) + 1e-30))
             worst = min(worst, cos)
+            print('CALIB effdet %s %s %.4f' % (tag, name, np.linalg.norm(got - ref) / np.linalg.norm(ref)))
             # (the stem sits behind every bf16-stored activation of the network: D2 at 128 x 256 measures 0.949 - 0.96
             #  there, depending on which depthwise forms round swish(z) to bf16 before the multiply)
             assert cos > (0.93 if '_conv_stem' in name else 0.95) and 0.8 < ratio < 1.25, (name, cos, ratio)
@@ -174,6 +175,7 @@ def test_drop_connect_vs_reference_golden(golden_dir):
                 assert np.abs(got - ref).max() <= 1e-5 * gn, name
                 continue
             cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+            print('CALIB effdet_dc %s %.4f' % (name, np.linalg.norm(got - ref) / np.linalg.norm(ref)))
             assert cos > 0.95, (name, cos)
     # all branches kept (u = 1 - tiny): out = branch / keep + skip; all dropped (u = 0, rate > 0): out = skip
     plan.dc_inject = torch.full_like(plan.dc_inject, 0.999999)

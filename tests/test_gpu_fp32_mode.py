@@ -210,9 +210,17 @@ def _effdet_check(g, model, img, ann, dev):
             rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
             if rel > worst[1]:
                 worst = (name, rel)
-            # (no fp64 run in these goldens: the 1e-3 bound of the verdict, 3e-3 for the SE / stem tensors whose sums
-            #  cancel like RetinaNet's conv1.weight)
-            assert rel <= 3e-3, (name, rel)
+            k64 = 'grad64/%s/val' % name
+            if k64 in g.files:
+                # the rule of the RetinaNet goldens: 1e-3, or three times the distance of the reference's OWN fp32 run
+                # from the same model evaluated in float64 (tools/make_golden.py:_add_fp64_run) where that is larger
+                ref64 = g[k64].astype(np.float64)
+                noise = float(np.linalg.norm(ref - ref64) / np.linalg.norm(ref64))
+                assert rel <= max(1e-3, 3.0 * noise), (name, rel, noise)
+            else:
+                # (the drop-connect golden has no fp64 run - its torch.rand draws are fp32 -: 3e-3 for the SE / stem
+                #  tensors whose sums cancel like RetinaNet's conv1.weight)
+                assert rel <= 3e-3, (name, rel)
     print('fp32 EfficientDet: cls %.7g (ref %.7g) reg %.7g (ref %.7g) worst sampled-grad relL2 %s %.3g'
           % (cl.item(), g['cls_loss'].item(), rl.item(), g['reg_loss'].item(), worst[0], worst[1]))
 

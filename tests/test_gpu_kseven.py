@@ -97,6 +97,7 @@ def test_kseven_vs_reference_golden(golden_dir, tag, precision):
                 assert e32 <= max(1e-3, 3.0 * noise), (name, e32, noise)
             else:
                 cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+                print('CALIB kseven %s %s %.4f' % (tag, name, e32))
                 assert cos > (0.8 if name == 'backbone.conv1.weight' else 0.93), (name, cos)
     print('%s %s: cls %.6g (ref %.6g) worst sampled-grad relL2 %s %.3g' % (tag, precision, cl.item(), g['cls_loss'].item(), worst[0], worst[1]))
     # decode tail (ksevendet.py:253-286) runs through the shared device path

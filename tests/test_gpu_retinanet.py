@@ -76,7 +76,12 @@ def test_heads_losses_grads_vs_reference_golden(golden_dir, dev, tag):
             cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
             ratio = float(np.linalg.norm(got) / (np.linalg.norm(ref) + 1e-30))
             worst = min(worst if worst else 1.0, cos)
-            assert cos > 0.95 and 0.8 < ratio < 1.25, (name, cos, ratio)
+            rl2 = float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))
+            print('  golden relL2 %-44s %.4f (cos %.4f, norm ratio %.3f)' % (name, rl2, cos, ratio))
+            # relative L2 per tensor against the fp32 reference (no cosine gate): about twice the spread of the bf16
+            # plan against its own bf16 twin (TWIN_* below), measured here 0.036 / 0.127 general, 0.098 / 0.263 stem
+            assert rl2 <= _bound(GOLDEN_REL_L2, tag, name), (name, rl2)
+            assert 0.95 < ratio < 1.05, (name, ratio)
     print('worst sampled-grad cosine', worst)
 
 
@@ -86,8 +91,23 @@ def test_heads_losses_grads_vs_reference_golden(golden_dir, dev, tag):
 # that order causes; bounds = 2x the spread measured on MI355X (printed by the test).  conv1.weight is the
 # ill-conditioned one: each element sums ~32 768 random-sign terms (the reference's own fp32 run is 3.3e-3 from
 # its fp64 value there, 10x its other backbone tensors: tests/golden `grad64/*`), so bf16 noise shows 10x as well.
-TWIN_REL_L2 = {'r18_256': 0.20, 'r50_128x160': 0.40}        # measured worst: 0.096 (fpn.P5_2.bias) / 0.219 (fpn.P7_2.bias: 1 x 2 cells)
-TWIN_REL_L2_STEM = 0.5
+# Measured on MI355X (deterministic kernels: the same on every box), r18_256 / r50_128x160 (one image, 4 x 5 cells in layer4):
+#   general        0.035 / 0.154 (layer3.3.bn1.bias)           -> 0.055 / 0.23   (1.5 x)
+#   conv1.weight   0.052 / 0.194                               -> 0.08  / 0.30
+#   fpn.P7_2.*     0.070 / 0.219 (1 x 2 cells at 128 x 160)    -> 0.11  / 0.33
+#   fpn.P5_2.*     0.104 / (general)                           -> 0.16
+TWIN_REL_L2 = {'r18_256': {'': 0.055, 'conv1.weight': 0.08, 'fpn.P7_2.': 0.11, 'fpn.P5_2.': 0.16},
+               'r50_128x160': {'': 0.23, 'conv1.weight': 0.30, 'fpn.P7_2.': 0.33}}
+# the same plan against the reference's fp32 goldens: ~2 x the twin spread per class
+GOLDEN_REL_L2 = {'r18_256': {'': 0.07, 'conv1.weight': 0.15, 'fpn.P7_2.': 0.16, 'fpn.P5_2.': 0.20},
+                 'r50_128x160': {'': 0.25, 'conv1.weight': 0.40, 'fpn.P7_2.': 0.40}}
+
+
+def _bound(table, tag, name):
+    """Longest matching name prefix of the tag's table ('' = every other tensor)."""
+    t = table[tag]
+    best = max((k for k in t if name.startswith(k)), key=len)
+    return t[best]
 
 
 @pytest.mark.parametrize('tag', ['r18_256', 'r50_128x160'])
@@ -125,8 +145,10 @@ def test_vs_oracle_same_bf16_rounded_weights(golden_dir, dev, tag):
         rows.append((float((got - ref).norm() / ref.norm()), name))
     rows.sort(reverse=True)
     print('bf16 plan vs bf16 twin, %s: worst per-tensor relL2 %s' % (tag, ['%s %.3f' % (n, r) for r, n in rows[:6]]))
+    for r, n in rows:
+        print('  twin relL2 %-44s %.4f' % (n, r))
     for r, name in rows:
-        assert r <= (TWIN_REL_L2_STEM if name == 'conv1.weight' else TWIN_REL_L2[tag]), (name, r)
+        assert r <= _bound(TWIN_REL_L2, tag, name), (name, r)
 
 
 def test_decode_tail_vs_golden(golden_dir, dev):
@@ -207,6 +229,7 @@ def test_three_level_variants_vs_reference_golden(golden_dir, dev, tag):
                 continue
             cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
             ratio = float(np.linalg.norm(got) / (np.linalg.norm(ref) + 1e-30))
+            print('CALIB variant %s %s %.4f' % (kind, name, np.linalg.norm(got - ref) / np.linalg.norm(ref)))
             assert cos > 0.95 and 0.8 < ratio < 1.25, (name, cos, ratio)
     model.eval()
     s, c, b = model(img[:1]) if kind == 'tiny' else model(img[:1], return_loss=False)

@@ -36,6 +36,12 @@ def agg(d):
 def main():
     fdir, wdir, steps, dst = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     f, w = agg(fdir), agg(wdir)
+    # the number of training steps the profiled command really ran (bench.py adds host-cost probes to its warm-up and
+    # timed steps): one adamw_prepare launch per optimizer step
+    marks = [v[0] for k, v in f.items() if k.startswith('adamw_prepare_kernel')]
+    if marks and marks[0] != steps:
+        print('collect_traffic: %d optimizer steps in the trace (argument said %d)' % (marks[0], steps))
+        steps = marks[0]
     kern = {}
     for k in sorted(f, key=lambda k: -f[k][1]):
         rd = 2.0 * f[k][1] * 1024 / steps

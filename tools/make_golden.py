@@ -316,7 +316,7 @@ def _add_fp64_run(d, model, img_t, ann_t, call, keys):
     model.zero_grad()
     cl, rl = call(model, img_t.double(), ann_t.double())
     (cl.mean() + rl.mean()).backward()
-    g64 = {k: p.grad.numpy().copy() for k, p in model.named_parameters()}
+    g64 = {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
     d['cls_loss64'], d['reg_loss64'] = cl.detach().numpy(), rl.detach().numpy()
     for k in keys:
         d['grad64/' + k + '/val'] = g64[k].reshape(-1)[d['grad/' + k + '/idx']]
@@ -687,9 +687,62 @@ def gen_e2e_effdet(coef, H, W, B, num_classes, tag, gain, head_std):
     with torch.no_grad():
         s, c, b = model(img_t[:1], return_loss=False)
     d['det_scores'], d['det_classes'], d['det_boxes'] = s.numpy(), c.numpy(), b.numpy()
+    # the same model in float64: the yardstick for the fp32-mode gradient bound (as for RetinaNet, _add_fp64_run)
+    _add_fp64_run(d, model, img_t, ann_t, lambda m, i, a: m(i, a), [k for k in EFF_GRAD_KEYS if k in grads])
+    model.float()
     np.savez_compressed(os.path.join(OUT, 'e2e_%s.npz' % tag), **d)
     print('e2e', tag, 'cls', cl.item(), 'reg', rl.item(), 'dets', s.shape, 'gnorm', d['grad_global_norm'],
           'cls range', float(cls.min()), float(cls.max()))
+
+
+def gen_effdet_trainbn(coef, H, W, B, num_classes, tag, gain, head_std):
+    """EfficientDet with every BatchNorm2d left in TRAIN mode (`model.train()` without `freeze_bn()`; what
+    `replace_w_sync_bn(model)` + train() computes on one replica, utils/sync_batchnorm/batchnorm.py:65-69): batch
+    statistics in the stem, the three BNs of every MBConv block (expand / depthwise / project), the BiFPN's
+    down-channel and separable convs and the heads' per-level BNs; running statistics after ONE forward (momentum
+    0.01, eps 1e-3, efficientdet.py:36, utils_efficientnet.py GlobalParams); drop-connect off."""
+    from architectures import efficientdet as ref_eff
+    torch.manual_seed(0)
+    model = ref_eff.build_efficientdet('efficientdet-d%d' % coef, num_classes=num_classes)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+
+    def load():
+        sd = synth.synth_state_dict(shapes, seed=0, gain=gain, head_std=head_std)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    load()
+    model.train()
+    synth.disable_drop_connect(model)
+    img = synth.synth_images(B, H, W, seed=1)
+    ann = synth.synth_annotations(B, H, W, num_real=6, pad_to=8, num_classes=num_classes, seed=2)
+    img_t, ann_t = torch.from_numpy(img), torch.from_numpy(ann)
+    cl, rl = model(img_t, ann_t)
+    model.zero_grad()
+    (cl.mean() + rl.mean()).backward()
+    grads = {k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+    d = dict(cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(), coef=np.array(coef), hw=np.array([H, W]),
+             batch=np.array(B), num_classes=np.array(num_classes), gain=np.array(gain), head_std=np.array(head_std))
+    keys = [k for k in EFF_GRAD_KEYS if k in grads] + [
+        'backbone_net.model._blocks.0._bn1.weight', 'backbone_net.model._blocks.3._bn0.bias',
+        'backbone_net.model._blocks.7._bn2.weight', 'bifpn.0.p4_down_channel.1.bias',
+        'regressor.bn_list.0.1.weight', 'classifier.bn_list.2.0.bias', 'classifier.bn_list.4.2.weight']
+    for k in keys:
+        flat = grads[k].reshape(-1)
+        sel = np.linspace(0, flat.size - 1, min(flat.size, 512)).astype(np.int64)
+        d['grad/' + k + '/idx'] = sel
+        d['grad/' + k + '/val'] = flat[sel]
+        d['grad/' + k + '/norm'] = np.array(np.sqrt((grads[k].astype(np.float64) ** 2).sum()))
+    d['grad_global_norm'] = np.array(np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in grads.values())))
+    sd = model.state_dict()
+    for k in ('backbone_net.model._bn0', 'backbone_net.model._blocks.0._bn1', 'backbone_net.model._blocks.4._bn0',
+              'backbone_net.model._blocks.15._bn2', 'bifpn.0.p5_to_p6.1', 'bifpn.1.conv4_up.bn',
+              'regressor.bn_list.4.0', 'classifier.bn_list.0.2'):
+        d['running/' + k + '.running_mean'] = sd[k + '.running_mean'].numpy().copy()
+        d['running/' + k + '.running_var'] = sd[k + '.running_var'].numpy().copy()
+        d['running/' + k + '.num_batches_tracked'] = sd[k + '.num_batches_tracked'].numpy().copy()
+    load()                                                        # (the fp32 forward moved the running statistics)
+    _add_fp64_run(d, model, img_t, ann_t, lambda m, i, a: m(i, a), keys)
+    np.savez_compressed(os.path.join(OUT, 'e2e_%s.npz' % tag), **d)
+    print('e2e', tag, 'cls', cl.item(), 'reg', rl.item(), 'gnorm', d['grad_global_norm'])
 
 
 def gen_effdet_drop_connect(coef, H, W, B, num_classes, tag, gain, head_std):
@@ -775,6 +828,8 @@ if __name__ == '__main__':
     if 'effdet' in which:
         gen_e2e_effdet(0, 128, 128, 2, 8, 'effdet_d0_128', 1.0, 0.05)      # configs[3] family
         gen_e2e_effdet(2, 128, 256, 1, 5, 'effdet_d2_128x256', 1.0, 0.05)  # configs[4] family
+    if 'effdet_trainbn' in which:
+        gen_effdet_trainbn(0, 128, 256, 3, 8, 'effdet_d0_trainbn_128x256', 1.0, 0.05)
     if 'effdet_dc' in which:
         gen_effdet_drop_connect(0, 128, 128, 4, 8, 'effdet_d0_dropconnect_128', 1.0, 0.05)
     if 'effdet6' in which:
