@@ -103,15 +103,38 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* __restrict__ 
     }
 }
 
-// sums[2C] = sum over blocks (index order, double); backward: dgamma += sums[C + c], dbeta += sums[c]
+// sums[2C] = sum over the partial blocks; backward: dgamma += sums[C + c], dbeta += sums[c].
+// A block owns 8 columns; its 32 row groups each add every 32nd partial row (four independent loads in flight, double
+// accumulation), and one thread per column adds the 32 group sums in group order: a fixed order, so bit-reproducible,
+// and ~nblk / 32 dependent loads deep instead of nblk (one thread per column walking up to 1024 partial rows measured
+// 204 us per launch: 42 % of the GPU time of a synchronised-BN step, profiles/r03_syncbn_kernel_stats_before.txt).
+constexpr int RED_COLS = 8, RED_GROUPS = 32;
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ partials, int nblk, int C,
                                                         float* __restrict__ sums, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
+    __shared__ double red[RED_GROUPS][RED_COLS];
+    const int col = threadIdx.x % RED_COLS, grp = threadIdx.x / RED_COLS;
+    const int i = blockIdx.x * RED_COLS + col;
+    const long long stride = 2LL * C;
     double acc = 0.0;
-    for (int b = 0; b < nblk; ++b) acc += (double)partials[(long long)b * 2 * C + i];
-    const float v = (float)acc;
+    if (i < 2 * C) {
+        int b = grp;
+        for (; b + 3 * RED_GROUPS < nblk; b += 4 * RED_GROUPS) {
+            const float v0 = partials[(long long)b * stride + i];
+            const float v1 = partials[(long long)(b + RED_GROUPS) * stride + i];
+            const float v2 = partials[(long long)(b + 2 * RED_GROUPS) * stride + i];
+            const float v3 = partials[(long long)(b + 3 * RED_GROUPS) * stride + i];
+            acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+        }
+        for (; b < nblk; b += RED_GROUPS) acc += (double)partials[(long long)b * stride + i];
+    }
+    red[grp][col] = acc;
+    __syncthreads();
+    if (grp != 0 || i >= 2 * C) return;
+    double tot = 0.0;
+#pragma unroll
+    for (int g = 0; g < RED_GROUPS; ++g) tot += red[g][col];
+    const float v = (float)tot;
     sums[i] = v;
     if (i < C) { if (dbeta) dbeta[i] += v; }
     else if (dgamma) dgamma[i - C] += v;
@@ -226,7 +249,7 @@ extern "C" int mi355_bn_nhwc_stats(const void* a, const void* b, const float* st
 extern "C" int mi355_bn_nhwc_reduce(const float* partials, int nblk, int C, float* sums, float* dgamma, float* dbeta,
                                     void* stream) {
     MI355_REQUIRE(partials && sums && nblk > 0 && C > 0, "bn_nhwc_reduce: bad args");
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)cdiv(2 * C, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)cdiv(2 * C, RED_COLS)), dim3(256), 0, (hipStream_t)stream,
                        partials, nblk, C, sums, dgamma, dbeta);
     return check_launch("bn_reduce_kernel");
 }

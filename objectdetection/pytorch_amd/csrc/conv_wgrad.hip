@@ -102,6 +102,8 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
     if (L.ub > 1) {
         const int idx = blockIdx.x >> 3;
         b = ((blockIdx.x & 7) + 8 * (idx / L.ub)) * L.ub + idx % L.ub;
+    } else if (L.xs) {
+        b = xcd_swizzle(blockIdx.x, gridDim.x);         // no exact unit split: contiguous logical ranges per XCD
     }
     const int c_tile = b % L.c_tiles;  b /= L.c_tiles;
     const int k_tile = b % L.k_tiles;  b /= L.k_tiles;
@@ -1174,7 +1176,9 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
         const char* e = getenv("MI355_WG_XCD");
         return e ? atoi(e) : 1;
     }();
-    L.xs = (xcd_mode && row3 && grid <= (row3x ? 256 : 512)) ? 1 : 0;
+    // (equal chunks - one problem - keep the XCDs balanced at any grid size; the longest-first chunk order of a grouped
+    //  launch does so only while every block is resident at once)
+    L.xs = (xcd_mode && (row3 ? grid <= (row3x ? 256 : 512) : (L.ub == 1 && (in.nprob == 1 || grid <= 512)))) ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));

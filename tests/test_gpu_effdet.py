@@ -31,6 +31,19 @@ def _build(tag, golden_dir, drop_connect=False):
     return g, model, img, ann, sd, coef, nc
 
 
+# measured worst relL2 (stem / first MBConv block / everything else): d0 0.133 / 0.090 / 0.083, d2 0.319 / 0.167 / 0.126,
+# d6 0.255 / 0.235 / 0.064, d0 with drop-connect 0.187 / 0.102 / 0.077
+_STEM, _B0 = 'backbone_net.model._conv_stem', 'backbone_net.model._blocks.0.'
+BF16_REL_L2 = {'effdet_d0_128': {'': 0.125, _STEM: 0.20, _B0: 0.14},
+               'effdet_d2_128x256': {'': 0.19, _STEM: 0.48, _B0: 0.25},
+               'effdet_d6_128': {'': 0.10, _STEM: 0.39, _B0: 0.36},
+               'effdet_d0_dropconnect_128': {'': 0.115, _STEM: 0.28, _B0: 0.16}}
+
+
+def _bound(table, name):
+    return table[max((k for k in table if name.startswith(k)), key=len)]
+
+
 @pytest.mark.parametrize('tag', ['effdet_d0_128', 'effdet_d2_128x256', 'effdet_d6_128'])
 def test_effdet_vs_reference_golden(golden_dir, tag):
     g, model, img, ann, sd, coef, nc = _build(tag, golden_dir)
@@ -83,10 +96,11 @@ def test_effdet_vs_reference_golden(golden_dir, tag):
             cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
             ratio = float(np.linalg.norm(got) / (np.linalg.norm(ref) + 1e-30))
             worst = min(worst, cos)
-            print('CALIB effdet %s %s %.4f' % (tag, name, np.linalg.norm(got - ref) / np.linalg.norm(ref)))
-            # (the stem sits behind every bf16-stored activation of the network: D2 at 128 x 256 measures 0.949 - 0.96
-            #  there, depending on which depthwise forms round swish(z) to bf16 before the multiply)
-            assert cos > (0.93 if '_conv_stem' in name else 0.95) and 0.8 < ratio < 1.25, (name, cos, ratio)
+            rl2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            # per-tensor relative L2 against the fp32 reference, 1.5 x what MI355X measures per class (the kernels are
+            # deterministic); the stem and the first block sit behind every bf16-stored activation of the network
+            assert rl2 <= _bound(BF16_REL_L2[tag], name), (name, rl2)
+            assert 0.9 < ratio < 1.1, (name, ratio)
     print(tag, 'worst sampled-grad cosine', worst)
 
 
@@ -174,9 +188,8 @@ def test_drop_connect_vs_reference_golden(golden_dir):
             if np.linalg.norm(ref) < 1e-5 * gn:
                 assert np.abs(got - ref).max() <= 1e-5 * gn, name
                 continue
-            cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
-            print('CALIB effdet_dc %s %.4f' % (name, np.linalg.norm(got - ref) / np.linalg.norm(ref)))
-            assert cos > 0.95, (name, cos)
+            rl2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            assert rl2 <= _bound(BF16_REL_L2['effdet_d0_dropconnect_128'], name), (name, rl2)
     # all branches kept (u = 1 - tiny): out = branch / keep + skip; all dropped (u = 0, rate > 0): out = skip
     plan.dc_inject = torch.full_like(plan.dc_inject, 0.999999)
     kept = [x.item() for x in model(img, ann)]

@@ -49,6 +49,13 @@ def build(g, dev, precision):
     return model
 
 
+# measured (stem, worst other tensor): fpn 0.101 / 0.044, panet 0.114 / 0.090, headbn 0.279 / 0.237, bifpn 0.160 / 0.107,
+# bifpn2 0.201 / 0.145
+BF16_REL_L2 = {'kseven_r18_fpn_128x160': (0.16, 0.07), 'kseven_r18_panet_128': (0.18, 0.14),
+               'kseven_r18_headbn_128': (0.42, 0.36), 'kseven_r18_bifpn_128x256': (0.24, 0.16),
+               'kseven_r18_bifpn2_128': (0.30, 0.22)}
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 @pytest.mark.parametrize('tag', ['kseven_r18_fpn_128x160', 'kseven_r18_panet_128', 'kseven_r18_headbn_128',
                                  'kseven_r18_bifpn_128x256', 'kseven_r18_bifpn2_128'])
@@ -96,9 +103,10 @@ def test_kseven_vs_reference_golden(golden_dir, tag, precision):
             if f32:
                 assert e32 <= max(1e-3, 3.0 * noise), (name, e32, noise)
             else:
-                cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
-                print('CALIB kseven %s %s %.4f' % (tag, name, e32))
-                assert cos > (0.8 if name == 'backbone.conv1.weight' else 0.93), (name, cos)
+                # bf16 plan against the fp32 reference, per-tensor relative L2: 1.5 x the measured worst of the tag
+                # (stem / everything else; train-mode head BN over 4 x 1 cells spreads the rounding: headbn)
+                stem, rest = BF16_REL_L2[tag]
+                assert e32 <= (stem if name == 'backbone.conv1.weight' else rest), (name, e32)
     print('%s %s: cls %.6g (ref %.6g) worst sampled-grad relL2 %s %.3g' % (tag, precision, cl.item(), g['cls_loss'].item(), worst[0], worst[1]))
     # decode tail (ksevendet.py:253-286) runs through the shared device path
     model.eval()

@@ -229,8 +229,9 @@ def test_three_level_variants_vs_reference_golden(golden_dir, dev, tag):
                 continue
             cos = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
             ratio = float(np.linalg.norm(got) / (np.linalg.norm(ref) + 1e-30))
-            print('CALIB variant %s %s %.4f' % (kind, name, np.linalg.norm(got - ref) / np.linalg.norm(ref)))
-            assert cos > 0.95 and 0.8 < ratio < 1.25, (name, cos, ratio)
+            rl2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            # per-tensor relative L2 against the fp32 reference: 1.5 x the measured worst (tiny 0.113, p45p6 0.124)
+            assert rl2 <= {'tiny': 0.17, 'p45p6': 0.19}[kind] and 0.9 < ratio < 1.1, (name, rl2, ratio)
     model.eval()
     s, c, b = model(img[:1]) if kind == 'tiny' else model(img[:1], return_loss=False)
     ref_s = g['det_scores']

@@ -61,3 +61,25 @@ for key, a in sorted(agg.items(), key=lambda kv: -kv[1][2]):
     print('%-3s %-7s np%d C%-4d K%-4d %dx%d s%d %-26s n=%-2d %8.1f us/launch %7.1f TF/s  %5.1f%% of time  floor %6.1f us  lost %7.1f us'
           % (key + (a[0], a[2] / a[0], a[1] / a[2] / 1e6, 100 * a[2] / tot_t, a[3] / a[0], a[2] - a[3])))
 print('sum of floors (max(bytes / 5 TB/s, flops / 1.2 PF/s)): %.2f ms' % (sum(r[11] for r in rows) / 1e3))
+
+# ---- what a launch boundary costs: the same conv launches in PLAN ORDER on one stream (every launch reads what its
+# predecessor just wrote, caches as the step leaves them) against the sum of the alone times above (each launch replayed
+# five times over the same operands, i.e. warm).  The difference per launch is what fusing two dependent launches into
+# one can at most win on top of the bytes it stops moving.
+CONV = ('mi355_conv_gather', 'mi355_conv_gather_splitk', 'mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_multi')
+s = ctypes.c_void_p(st.cuda_stream)
+for phase, steps in (('fwd', plan.fwd_steps), ('bwd', plan.bwd_steps)):
+    chain = [(fn, args) for fn, args, name in steps if name in CONV]
+    alone = sum(r[10] for r in rows if r[0] == phase)
+    for fn, args in chain:
+        fn(*args, s)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(5):
+        for fn, args in chain:
+            fn(*args, s)
+    e1.record(st); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 5 * 1e3
+    print('%s: %d conv launches in plan order on one stream %.2f ms; sum of their alone times %.2f ms; %.2f us per launch boundary'
+          % (phase, len(chain), us / 1e3, alone / 1e3, (us - alone) / max(len(chain), 1)))
