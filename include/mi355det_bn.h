@@ -35,9 +35,18 @@ int mi355_bn_nhwc_stats(const void* a, const void* b, const float* state, int f3
  * dgamma (+)= sums[1], dbeta (+)= sums[0] when given (backward: the LOCAL sums are the parameter gradients). */
 int mi355_bn_nhwc_reduce(const float* partials, int nblk, int C, float* sums, float* dgamma, float* dbeta,
                          void* stream);
+/* As mi355_bn_nhwc_reduce, and sums[2C], sums[2C + 1] = this replica's element count per channel (`local_count` = its
+ * N*H*W) split as floor(count / 4096), count mod 4096 - both exact in fp32 and exact under the SUM all-reduce of up to
+ * 4096 replicas.  The reference's SynchronizedBatchNorm2d adds the ACTUAL sizes of the replicas
+ * (utils/sync_batchnorm/batchnorm.py:105-126 `sum_size`), which nn.DataParallel's scatter makes unequal when the batch
+ * does not divide; sums has 2C + 2 elements and all of them go through the exchange. */
+int mi355_bn_nhwc_reduce_counted(const float* partials, int nblk, int C, int64_t local_count, float* sums, float* dgamma,
+                                 float* dbeta, void* stream);
 /* sums (all-reduced over the replicas when synchronised) + element count -> layer state; running statistics
  * (may be NULL) updated with `momentum` and the UNBIASED variance; *num_batches_tracked += 1 when given.
  * sync_clamp != 0: invstd = clamp(biased var, eps)^-1/2 (batchnorm.py:145); 0: (biased var + eps)^-1/2. */
+/* count <= 0: the count is read from sums[2C .. 2C + 2) (mi355_bn_nhwc_reduce_counted, after the exchange) and
+ * state[5C] = 1 / count is stored for the backward pass (state then has 5C + 1 elements). */
 int mi355_bn_nhwc_finalize(const float* sums, float count, int C, float eps, float momentum, int sync_clamp,
                            const float* gamma, const float* beta, float* running_mean, float* running_var,
                            int64_t* num_batches_tracked, float* state, void* stream);
@@ -46,6 +55,7 @@ int mi355_bn_nhwc_apply(const void* z, const float* state, const void* addend, i
                         void* y, void* stream);
 /* dz = scale * (g - (sums[0] + zhat * through * sums[1]) * inv_count), zhat = (z - mean)*invstd; sums = the
  * (all-reduced) backward sums, inv_count = 1 / total element count per channel over the replicas. */
+/* inv_count <= 0: read from state[5C] (the counted form of mi355_bn_nhwc_finalize). */
 int mi355_bn_nhwc_bwd_apply(const void* g, const void* z, const float* state, const float* sums, float inv_count,
                             int f32, int64_t M, int C, void* dz, void* stream);
 

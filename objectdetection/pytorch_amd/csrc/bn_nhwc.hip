@@ -111,8 +111,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const void* __restrict__ 
 constexpr int RED_COLS = 8, RED_GROUPS = 32;
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ partials, int nblk, int C,
                                                         float* __restrict__ sums, float* __restrict__ dgamma,
-                                                        float* __restrict__ dbeta) {
+                                                        float* __restrict__ dbeta, long long local_count) {
     __shared__ double red[RED_GROUPS][RED_COLS];
+    if (local_count > 0 && blockIdx.x == 0 && threadIdx.x == 0) {       // the replica's element count rides the exchange
+        sums[2 * C] = (float)(local_count >> 12);
+        sums[2 * C + 1] = (float)(local_count & 4095);
+    }
     const int col = threadIdx.x % RED_COLS, grp = threadIdx.x / RED_COLS;
     const int i = blockIdx.x * RED_COLS + col;
     const long long stride = 2LL * C;
@@ -148,7 +152,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c == 0 && nbt) *nbt += 1;
     if (c >= C) return;
-    const double n = (double)count;
+    double n = (double)count;
+    if (count <= 0.0f) {                                 // counted form: the all-reduced element count of the replicas
+        n = (double)sums[2 * C] * 4096.0 + (double)sums[2 * C + 1];
+        if (c == 0) state[MI355_BN_STATE_ROWS * C] = (float)(1.0 / n);
+    }
     const double s = (double)sums[c], ss = (double)sums[C + c];
     const double mean = s / n;
     double sumvar = ss - s * mean;                       // batchnorm.py:131-132
@@ -206,6 +214,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
                                                            float inv_count, long long n8, int C, void* __restrict__ dz) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n8) return;
+    if (inv_count <= 0.0f) inv_count = state[MI355_BN_STATE_ROWS * C];
     const int c0 = (int)((i * 8) % C);
     float vg[8], vz[8];
     load8<F32>(g, i * 8, vg);
@@ -250,14 +259,23 @@ extern "C" int mi355_bn_nhwc_reduce(const float* partials, int nblk, int C, floa
                                     void* stream) {
     MI355_REQUIRE(partials && sums && nblk > 0 && C > 0, "bn_nhwc_reduce: bad args");
     hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)cdiv(2 * C, RED_COLS)), dim3(256), 0, (hipStream_t)stream,
-                       partials, nblk, C, sums, dgamma, dbeta);
+                       partials, nblk, C, sums, dgamma, dbeta, 0LL);
+    return check_launch("bn_reduce_kernel");
+}
+
+extern "C" int mi355_bn_nhwc_reduce_counted(const float* partials, int nblk, int C, int64_t local_count, float* sums,
+                                            float* dgamma, float* dbeta, void* stream) {
+    MI355_REQUIRE(partials && sums && nblk > 0 && C > 0 && local_count > 0 && local_count < (1LL << 36),
+                  "bn_nhwc_reduce_counted: bad args");
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((unsigned)cdiv(2 * C, RED_COLS)), dim3(256), 0, (hipStream_t)stream,
+                       partials, nblk, C, sums, dgamma, dbeta, (long long)local_count);
     return check_launch("bn_reduce_kernel");
 }
 
 extern "C" int mi355_bn_nhwc_finalize(const float* sums, float count, int C, float eps, float momentum, int sync_clamp,
                                       const float* gamma, const float* beta, float* running_mean, float* running_var,
                                       int64_t* num_batches_tracked, float* state, void* stream) {
-    MI355_REQUIRE(sums && state && C > 0 && count > 0.0f, "bn_nhwc_finalize: bad args");
+    MI355_REQUIRE(sums && state && C > 0, "bn_nhwc_finalize: bad args");
     MI355_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_nhwc_finalize: running stats come in pairs");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count,
                        C, eps, momentum, sync_clamp, gamma, beta, running_mean, running_var,

@@ -85,6 +85,13 @@ __global__ __launch_bounds__(256) void conv_gather_f32_kernel(const FLaunch L) {
         s_outoff[tid] = oo;
         s_addoff[tid] = ao;
     }
+    // The epilogue reads the offsets from every wave.  The barriers of the k loop used to be the only ones in front of
+    // it, and a problem WITHOUT taps (the three empty parity classes of a 1x1 / stride-2 data gradient: dx = addend)
+    // has no k step: waves 1 .. 3 then read whatever the LDS held - offsets of the previous tile when the kernel ran
+    // alone (mostly harmless), another kernel's floats when the weight-gradient stream shared the CU: stores to wild
+    // addresses, the intermittent GPU memory fault of the fp32 mode (round 2's unexplained abort; found with
+    // MI355_TRACE at bwd[55] of the R50 plan, the data gradient of layer4.0.downsample).
+    __syncthreads();
 
     // staging: thread = (row = tid / 4, 4-float chunk = tid % 4) of both tiles
     const int srow = tid >> 2, chunk = tid & 3;

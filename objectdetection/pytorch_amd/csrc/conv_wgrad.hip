@@ -59,7 +59,7 @@ struct WLaunch {
     // grouped launches: chunks sorted by length (longest first), so that the short chunks of the small
     // pyramid levels fill the tail of the launch instead of opening a second round of full-length blocks
     int ub;                                     // XCD-local unit size in logical blocks (1: none)
-    int xs;                                     // row-of-taps kernels: blocks of one XCD take consecutive logical ids
+    int xs;                                     // > 0: XCD-aware block order in waves of xs blocks (wg_logical_block)
     int nsorted;                                // 0: chunk -> problem by chunk_begin (single problem)
     unsigned char ch_prob[MAX_SORTED];
     int ch_mbegin[MAX_SORTED];
@@ -79,6 +79,19 @@ __device__ __forceinline__ s4v lds_tr(unsigned addr) {
 __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs behind the wait (guide §5.4 rule 18)
+}
+
+// XCD-aware block order.  Consecutive blockIdx go round-robin over the 8 XCDs (one L2 each), and the (tap / kernel
+// row, k tile, c tile) blocks of a pixel chunk - consecutive LOGICAL ids - read the same dy / activation rows: in plain
+// order every chunk's rows are fetched into all eight L2s (PMC: 391 MB read per head-tower launch for 90 MB of operands).
+// Within each wave of `xs` blocks (the number resident at once: the dispatch order stays the logical order at that
+// granularity, so the longest-first chunk order of a grouped launch still leaves the shortest chunks for the tail) XCD x
+// takes a contiguous range of logical ids, i.e. whole chunks.  MI355_WG_XCD=0: plain order.
+__device__ __forceinline__ int wg_logical_block(int bid, int nblocks, int xs) {
+    if (xs <= 0) return bid;
+    const int base = (bid / xs) * xs;
+    const int n = min(xs, nblocks - base);
+    return base + xcd_swizzle(bid - base, n);
 }
 
 // KH (K <= 64, NG 1): the upper half of the k-tile is empty; the four waves take 64 x 32 column strips of the
@@ -102,8 +115,8 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
     if (L.ub > 1) {
         const int idx = blockIdx.x >> 3;
         b = ((blockIdx.x & 7) + 8 * (idx / L.ub)) * L.ub + idx % L.ub;
-    } else if (L.xs) {
-        b = xcd_swizzle(blockIdx.x, gridDim.x);         // no exact unit split: contiguous logical ranges per XCD
+    } else {
+        b = wg_logical_block(blockIdx.x, gridDim.x, L.xs);      // no exact unit split: contiguous logical ranges per XCD
     }
     const int c_tile = b % L.c_tiles;  b /= L.c_tiles;
     const int k_tile = b % L.k_tiles;  b /= L.k_tiles;
@@ -390,12 +403,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
     constexpr int NJ = KH ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // The (kernel row, k tile, c tile) blocks of a pixel chunk read the same dy / activation rows.  Consecutive
-    // blockIdx go round-robin over the 8 XCDs (one L2 each): in plain order every chunk's rows are fetched into all
-    // eight L2s (PMC: 425 MB read per head-tower launch for 90 MB of operands).  L.xs: XCD x takes a contiguous range
-    // of logical ids instead (xcd_swizzle), i.e. whole chunks; set when every block of the launch is resident at once,
-    // so that the longest-first chunk order cannot unbalance the XCDs (MI355_WG_XCD=0: plain order).
-    int b = L.xs ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    int b = wg_logical_block(blockIdx.x, gridDim.x, L.xs);
     const int c_tile = b % L.c_tiles;  b /= L.c_tiles;
     const int k_tile = b % L.k_tiles;  b /= L.k_tiles;
     const int kr = b % 3;              b /= 3;          // kernel row of this block
@@ -670,12 +678,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: scalar branches on the wave index
-    // The (kernel row, k tile, c tile) blocks of a pixel chunk read the same dy / activation rows.  Consecutive
-    // blockIdx go round-robin over the 8 XCDs (one L2 each): in plain order every chunk's rows are fetched into all
-    // eight L2s (PMC: 425 MB read per head-tower launch for 90 MB of operands).  L.xs: XCD x takes a contiguous range
-    // of logical ids instead (xcd_swizzle), i.e. whole chunks; set when every block of the launch is resident at once,
-    // so that the longest-first chunk order cannot unbalance the XCDs (MI355_WG_XCD=0: plain order).
-    int b = L.xs ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    int b = wg_logical_block(blockIdx.x, gridDim.x, L.xs);
     const int c_tile = b % L.c_tiles;  b /= L.c_tiles;
     const int k_tile = b % L.k_tiles;  b /= L.k_tiles;
     const int kr = b % 3;              b /= 3;          // kernel row of this block
@@ -1176,9 +1179,7 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
         const char* e = getenv("MI355_WG_XCD");
         return e ? atoi(e) : 1;
     }();
-    // (equal chunks - one problem - keep the XCDs balanced at any grid size; the longest-first chunk order of a grouped
-    //  launch does so only while every block is resident at once)
-    L.xs = (xcd_mode && (row3 ? grid <= (row3x ? 256 : 512) : (L.ub == 1 && (in.nprob == 1 || grid <= 512)))) ? 1 : 0;
+    L.xs = !xcd_mode ? 0 : (row3x ? 256 : 512);            // blocks resident at once: one / two per CU
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));

@@ -795,18 +795,24 @@ class RetinaPlan(object):
         nblk, rpb = c_int(), c_int()
         _lib.call('mi355_bn_nhwc_partial_blocks', c_i64(M), c_int(C), ctypes.byref(nblk), ctypes.byref(rpb))
         partials = self.new((nblk.value, 2 * C), torch.float32)
-        sums = self.new((2 * C,), torch.float32)
-        state = self.new((5 * C,), torch.float32)
         sync, group, world = self._bn_sync_group(bn)
+        # exchanged statistics carry each replica's own element count (batchnorm.py:105-126 adds the actual sizes: the
+        # last batch of an epoch, or a DataParallel scatter that does not divide, gives the replicas different N)
+        counted = sync and group_exchange(world)
+        sums = self.new((2 * C + (2 if counted else 0),), torch.float32)
+        state = self.new((5 * C + (1 if counted else 0),), torch.float32)
         f32 = c_int(1 if self.prec == 'fp32' else 0)
         lst = self.fwd_steps
         self._step(lst, 'mi355_bn_nhwc_stats', ptr(z), c_vp(0), c_vp(0), f32, c_i64(M), c_int(C), c_int(0), ptr(partials))
-        self._step(lst, 'mi355_bn_nhwc_reduce', ptr(partials), c_int(nblk.value), c_int(C), ptr(sums), c_vp(0), c_vp(0))
-        if sync and group_exchange(world):
+        if counted:
+            self._step(lst, 'mi355_bn_nhwc_reduce_counted', ptr(partials), c_int(nblk.value), c_int(C), c_i64(M), ptr(sums),
+                       c_vp(0), c_vp(0))
             self._bn_exchange_step(lst, sums, group)
+        else:
+            self._step(lst, 'mi355_bn_nhwc_reduce', ptr(partials), c_int(nblk.value), c_int(C), ptr(sums), c_vp(0), c_vp(0))
         track = bn.track_running_stats and bn.running_mean is not None
         plain = type(bn) is torch.nn.BatchNorm2d            # nn.BatchNorm2d.forward counts batches; the sync class does not
-        self._step(lst, 'mi355_bn_nhwc_finalize', ptr(sums), c_f32(float(M) * world), c_int(C), c_f32(bn.eps),
+        self._step(lst, 'mi355_bn_nhwc_finalize', ptr(sums), c_f32(0.0 if counted else float(M) * world), c_int(C), c_f32(bn.eps),
                    c_f32(bn.momentum), c_int(1 if sync else 0), ptr(bn.weight), ptr(bn.bias),
                    ptr(bn.running_mean if track else None), ptr(bn.running_var if track else None),
                    ptr(bn.num_batches_tracked if (track and plain) else None), ptr(state))
@@ -830,7 +836,9 @@ class RetinaPlan(object):
         if sync and group_exchange(world):
             self._bn_exchange_step(lst, gsums, group)
         dz = self.new(tuple(g.shape))
-        self._step(lst, 'mi355_bn_nhwc_bwd_apply', ptr(g), ptr(z), ptr(state), ptr(gsums), c_f32(1.0 / (float(M) * world)),
+        counted = sync and group_exchange(world)            # (1 / the exchanged element count sits in state[5C])
+        self._step(lst, 'mi355_bn_nhwc_bwd_apply', ptr(g), ptr(z), ptr(state), ptr(gsums),
+                   c_f32(0.0 if counted else 1.0 / (float(M) * world)),
                    f32, c_i64(M), c_int(C), ptr(dz))
         return dz
 

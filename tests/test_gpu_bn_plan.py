@@ -99,6 +99,66 @@ def test_bn_passes_vs_reference_syncbn_fixture(golden_dir, split, dtype):
         np.testing.assert_allclose(rv.cpu().numpy(), g['running_var1'], rtol=1e-5, atol=1e-6)
 
 
+def test_counted_forms_with_uneven_replicas(golden_dir):
+    """Replicas of DIFFERENT size (nn.DataParallel's scatter of a batch that does not divide; the reference adds the
+    actual sizes, utils/sync_batchnorm/batchnorm.py:105-126 `sum_size`): each replica's element count rides the
+    exchanged vector (mi355_bn_nhwc_reduce_counted), finalize and the backward pass read the summed count.  A 1 : 3
+    split of the fixture's rows must reproduce the one-replica result."""
+    L = _c()
+    from objectdetection.pytorch_amd._lib import c_f32, c_i64, c_int, c_vp, ptr
+    g = np.load(os.path.join(golden_dir, 'syncbn.npz'))
+    dev = torch.device('cuda', 0)
+    x = torch.from_numpy(g['x'])
+    N, C, H, W = x.shape
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    dyh = torch.from_numpy(g['dy']).permute(0, 2, 3, 1).contiguous().to(dev)
+    wt, bs = torch.from_numpy(g['weight']).to(dev), torch.from_numpy(g['bias']).to(dev)
+    eps, mom = float(g['eps']), float(g['momentum'])
+    rm0, rv0 = torch.from_numpy(g['running_mean0']).to(dev), torch.from_numpy(g['running_var0']).to(dev)
+    y1, dx1, dw1, db1, st1 = _bn_passes(xh, dyh, wt, bs, eps, mom, rm0.clone(), rv0.clone(), 1, 1)
+    rows, grows = xh.reshape(-1, C), dyh.reshape(-1, C)
+    M = rows.shape[0]
+    cut = M // 4 + 3                                      # uneven, and not a multiple of anything
+    parts = [(rows[:cut].contiguous(), grows[:cut].contiguous()), (rows[cut:].contiguous(), grows[cut:].contiguous())]
+    st = c_vp(torch.cuda.current_stream().cuda_stream)
+    f32 = c_int(1)
+
+    def partial(t, zz, state, bwd, count):
+        nblk, rpb = ctypes.c_int(), ctypes.c_int()
+        L.call('mi355_bn_nhwc_partial_blocks', c_i64(t.shape[0]), c_int(C), ctypes.byref(nblk), ctypes.byref(rpb))
+        pb = torch.empty((nblk.value, 2 * C), device=dev)
+        L.call('mi355_bn_nhwc_stats', ptr(t), ptr(zz) if bwd else c_vp(0), ptr(state), f32, c_i64(t.shape[0]), c_int(C),
+               c_int(1 if bwd else 0), ptr(pb), st)
+        out = torch.zeros(2 * C + 2, device=dev)
+        if count:
+            L.call('mi355_bn_nhwc_reduce_counted', ptr(pb), c_int(nblk.value), c_int(C), c_i64(t.shape[0]), ptr(out),
+                   c_vp(0), c_vp(0), st)
+        else:
+            L.call('mi355_bn_nhwc_reduce', ptr(pb), c_int(nblk.value), c_int(C), ptr(out), c_vp(0), c_vp(0), st)
+        return out
+    sums = sum(partial(xp, None, None, False, True) for xp, _ in parts)            # the all-reduce
+    assert float(sums[2 * C]) * 4096 + float(sums[2 * C + 1]) == M
+    state = torch.empty(5 * C + 1, device=dev)
+    rm, rv = rm0.clone(), rv0.clone()
+    L.call('mi355_bn_nhwc_finalize', ptr(sums), c_f32(0.0), c_int(C), c_f32(eps), c_f32(mom), c_int(1), ptr(wt), ptr(bs),
+           ptr(rm), ptr(rv), c_vp(0), ptr(state), st)
+    np.testing.assert_allclose(state[:5 * C].cpu().numpy(), st1.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(float(state[5 * C]), 1.0 / M, rtol=1e-6)
+    gs = sum(partial(gp, xp, state, True, False)[:2 * C] for xp, gp in parts).contiguous()
+    dxs = []
+    for xp, gp in parts:
+        d = torch.empty_like(xp)
+        L.call('mi355_bn_nhwc_bwd_apply', ptr(gp), ptr(xp), ptr(state), ptr(gs), c_f32(0.0), f32, c_i64(xp.shape[0]),
+               c_int(C), ptr(d), st)
+        dxs.append(d)
+    got = torch.cat(dxs).cpu().numpy()
+    ref = dx1.cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+    # with the replicas' counts taken as EQUAL (M / 2 each) the statistics would be wrong by construction: the test
+    # really exercises the count
+    assert cut * 2 != M
+
+
 def _trainbn_model(dev, g, precision):
     from objectdetection.pytorch_amd.architectures import retinanet
     depth, nc = int(g['depth']), int(g['num_classes'])

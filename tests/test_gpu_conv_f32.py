@@ -111,3 +111,31 @@ def test_conv_dgrad_wgrad_f32(dev, case):
     G = ops_conv.conv_wgrad(xh, dyh, R, R, stride, pad, split_rows=64, colsum=cs)        # [Kpad][T][C], atomics
     _close(G[:K].view(K, R, R, C).permute(0, 3, 1, 2), w.grad, 5e-6)
     _close(cs[:K], dy.double().sum(dim=(0, 2, 3)), 5e-6)
+
+
+def test_dgrad_without_taps_beside_a_wgrad_stream_f32(dev):
+    """The empty parity classes of a 1x1 / stride-2 data gradient (dx = addend at the odd rows / columns) have no k
+    step: the gather kernel's output-offset table must be published by a barrier of its own.  Round 2 / 3's intermittent
+    GPU memory fault of the fp32 mode was this launch (layer4.0.downsample) reading the table while the weight-gradient
+    stream's kernel shared the CU.  Here: the same launch pair on two streams, 20 times, result checked every time."""
+    from objectdetection.pytorch_amd import ops_conv
+    N, H, W, C, K = 4, 32, 32, 256, 512
+    x = _mk((N, C, H, W), 1).double().requires_grad_()
+    w = _mk((K, C, 1, 1), 2, scale=(2.0 / C) ** 0.5).double().requires_grad_()
+    y = F.conv2d(x, w, None, 2, 0)
+    dy = _mk(tuple(y.shape), 3)
+    add = _mk((N, C, H, W), 5)
+    y.backward(dy.double())
+    ref = x.grad + add.double()
+    _, w_dgr = _shadows(w.detach().float(), dev)
+    dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    addh = add.permute(0, 2, 3, 1).contiguous().to(dev)
+    xh = x.detach().float().permute(0, 2, 3, 1).contiguous().to(dev)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for _ in range(20):
+        with torch.cuda.stream(side):
+            ops_conv.conv_wgrad(xh, dyh, 1, 1, 2, 0, split_rows=64)
+        dx = ops_conv.conv_dgrad(dyh, w_dgr, H, W, C, 1, 1, 2, 0, addend=addh)
+        torch.cuda.synchronize()
+        _close(dx.permute(0, 3, 1, 2), ref)
