@@ -324,6 +324,11 @@ class RetinaPlan(object):
             return self._run_py(steps, stream, begin, end)
         arr, n, hosts, _ = self._compiled(steps)
         end = n if end is None else end
+        if hosts and torch.cuda.is_current_stream_capturing():
+            # (a torch.distributed call per BatchNorm layer cannot be part of a hipGraph; on an RCCL group the exchange
+            #  is a table step - mi355_rccl_allreduce_sum_f32 - and is captured with the launches around it)
+            raise _lib.Mi355Error('hipGraph capture of a plan with host-side steps (synchronised BatchNorm statistics '
+                                  'exchanged through torch.distributed on a non-RCCL group): use Trainer(graph=False)')
         side = side2 = None
         if self._side_active():
             side = self._side_stream().cuda_stream
