@@ -729,6 +729,62 @@ class RetinaPlan(object):
         self.fwd_launches.append((spec, [(N, P, Q)]))
         return out
 
+    # -- same-shape convs of different layers as ONE launch (per-problem weights, Mi355ConvProblem.weight / .bias) ----
+    # The three 3x3 smoothing convs of the pyramid (retinanet.py:53, :57, :61) are independent once the laterals exist;
+    # alone the 32^2 and 16^2 ones are 27 / 20 us launches of 128 / 32 tiles that cannot fill 256 CUs.
+    def _group_convs_ok(self, specs):
+        s0 = specs[0]
+        return (os.environ.get('MI355_FPN_GROUP', '1') == '1' and self.prec == 'bf16' and 2 <= len(specs) <= ops_conv.MAX_PROBLEMS and
+                type(self).conv is RetinaPlan.conv and type(self).conv_bwd is RetinaPlan.conv_bwd and
+                all((sp.K, sp.Kpad, sp.Cpad, sp.R, sp.S, sp.stride, sp.pad) == (s0.K, s0.Kpad, s0.Cpad, s0.R, s0.S, s0.stride, s0.pad)
+                    and not sp.bn_train and not getattr(sp, 's2d', False) for sp in specs))
+
+    def conv_group(self, specs, xs, act=ACT_NONE):
+        """conv(spec_i, x_i) for every i in one grouped gather launch (largest map first)."""
+        if not self._group_convs_ok(specs):
+            return [self.conv(sp, x, act) for sp, x in zip(specs, xs)]
+        outs, probs = [], []
+        for sp, x in zip(specs, xs):
+            N, H, W, C = x.shape
+            assert C == sp.Cpad, (sp.name, C, sp.Cpad)
+            pt, pl, P, Q = sp.geometry(H, W)
+            out = self.new((N, P, Q, sp.Kpad), zero=sp.Kpad != sp.K)
+            pr = fwd_problem(x, out.data_ptr(), sp.R, sp.S, sp.stride, (pt, pl), K=sp.K, out_size=(P, Q),
+                             out_strides=(P * Q * sp.Kpad, Q * sp.Kpad, sp.Kpad))
+            pr.weight = sp.w_fwd.data_ptr()
+            pr.bias = 0 if sp.bias_tensor is None else sp.bias_tensor.data_ptr()
+            outs.append(out)
+            probs.append(pr)
+            self.fwd_launches.append((sp, [(N, P, Q)]))
+        order = sorted(range(len(probs)), key=lambda i: -xs[i].shape[1] * xs[i].shape[2])
+        s0 = specs[order[0]]
+        self._gather(self.fwd_steps, [probs[i] for i in order], s0.w_fwd, s0.K, s0.T, bias=s0.bias_tensor, act=act)
+        return outs
+
+    def conv_bwd_group(self, specs, xs, dys):
+        """conv_bwd(spec_i, x_i, dy_i) with the data gradients of all i in one grouped launch -> [dx_i]."""
+        if not self._group_convs_ok(specs) or not all(sp.need_dgrad for sp in specs):
+            return [self.conv_bwd(sp, x, dy) for sp, x, dy in zip(specs, xs, dys)]
+        dxs, dprobs = [], []
+        for sp, x, dy in zip(specs, xs, dys):
+            N, H, W, C = x.shape
+            pt, pl, P, Q = sp.geometry(H, W)
+            pr = fwd_problem(x, dy.data_ptr(), sp.R, sp.S, sp.stride, (pt, pl), K=sp.Kpad, out_size=(P, Q))
+            if self._grouping_wgrads:
+                self._defer_wgrad(pr, sp, N * pr.P * pr.Q, x, dy)
+            else:
+                self._wgrad([pr], sp, N * pr.P * pr.Q)
+            dx = self.new((N, H, W, sp.Cpad))
+            ps = dgrad_problems(dy, dx.data_ptr(), H, W, sp.Cpad, sp.R, sp.S, sp.stride, pt)
+            assert len(ps) == 1 and pt == pl
+            ps[0].weight, ps[0].bias = sp.w_dgr.data_ptr(), 0
+            dprobs.append(ps[0])
+            dxs.append(dx)
+        order = sorted(range(len(dprobs)), key=lambda i: -xs[i].shape[1] * xs[i].shape[2])
+        s0 = specs[order[0]]
+        self._gather(self.bwd_steps, [dprobs[i] for i in order], s0.w_dgr, s0.Cpad, s0.T)
+        return dxs
+
     # ------------------------------------------------------------------ train-mode / synchronised BatchNorm
     def _pystep(self, lst, fn, name):
         """A host-side step inside a launch list (the cross-replica all-reduce of BN statistics): called as
@@ -915,11 +971,9 @@ class RetinaPlan(object):
         self.c3, self.c4, self.c5 = c3, c4, c5
         f = self.fpn
         self.p5lat = self.conv(f['P5_1'], c5)
-        self.p5 = self.conv(f['P5_2'], self.p5lat)
         self.p4lat = self.conv(f['P4_1'], c4, addend=self.p5lat, add_shift=1)
-        self.p4 = self.conv(f['P4_2'], self.p4lat)
         self.p3lat = self.conv(f['P3_1'], c3, addend=self.p4lat, add_shift=1)
-        self.p3 = self.conv(f['P3_2'], self.p3lat)
+        self.p3, self.p4, self.p5 = self.conv_group([f['P3_2'], f['P4_2'], f['P5_2']], [self.p3lat, self.p4lat, self.p5lat])
         self.p6 = self.conv(f['P6'], c5)
         self.p6relu = self.new(tuple(self.p6.shape))
         self._step(self.fwd_steps, 'mi355_relu_mask_bf16', ptr(self.p6), ptr(self.p6), ptr(self.p6relu),
@@ -1031,9 +1085,8 @@ class RetinaPlan(object):
         self.conv_bwd(f['P7_2'], self.p6relu, g_p7, dx=g_p6, addend=g_p6, mask=self.p6,
                       mask_first=not getattr(self, 'p6_relu_inplace', False))
         g_c5 = self.conv_bwd(f['P6'], self.c5, g_p6)
-        g_p5lat = self.conv_bwd(f['P5_2'], self.p5lat, g_p5)
-        g_p4lat = self.conv_bwd(f['P4_2'], self.p4lat, g_p4)
-        g_p3lat = self.conv_bwd(f['P3_2'], self.p3lat, g_p3)
+        g_p3lat, g_p4lat, g_p5lat = self.conv_bwd_group([f['P3_2'], f['P4_2'], f['P5_2']],
+                                                        [self.p3lat, self.p4lat, self.p5lat], [g_p3, g_p4, g_p5])
         self._sumpool(g_p3lat, g_p4lat)
         g_c3 = self.conv_bwd(f['P3_1'], self.c3, g_p3lat)
         self._sumpool(g_p4lat, g_p5lat)
