@@ -23,6 +23,8 @@ extern "C" {
 #define MI355_PLAN_MAIN 0   /* the main stream */
 #define MI355_PLAN_SIDE 1   /* the side stream, forked behind everything issued to main so far */
 #define MI355_PLAN_SIDE_RR 2 /* as SIDE, alternating between side and side2 when side2 is given */
+#define MI355_PLAN_JOIN 3   /* no launch (fn is ignored): main waits for everything issued to the side stream(s) so far -
+                               a join edge inside a list, e.g. behind a short independent branch that ran on the side stream */
 
 typedef struct Mi355PlanStep {
     int32_t fn;        /* index from mi355_plan_lookup(name); the entry point's last parameter is the stream */

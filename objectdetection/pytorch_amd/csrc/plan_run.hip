@@ -114,6 +114,14 @@ extern "C" int mi355_plan_run(const Mi355PlanStep* steps, int begin, int end, vo
     for (int i = begin; i < end; ++i) {
         const Mi355PlanStep& p = steps[i];
         if (p.host) { st->next = i; return 1; }
+        if (p.where == MI355_PLAN_JOIN) {                  // a join edge inside the list (side2 -> side -> main)
+            if (side_stream) {
+                const int rc = mi355_plan_join(main_stream, side_stream, side2_stream, st, 0);
+                if (rc) { st->failed = i; return rc; }
+                moved[0] = moved[1] = true;
+            }
+            continue;
+        }
         if (p.fn < 0 || p.fn >= g_count || p.nargs != g_table[p.fn].arity) {
             st->failed = i;
             return fail(MI355_EINVAL, "plan_run: step %d names entry point %d with %d arguments", i, p.fn, p.nargs);

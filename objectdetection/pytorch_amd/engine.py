@@ -35,7 +35,7 @@ def _ceil8(v):
 
 # ---------------------------------------------------------------------------------------------- plan tables
 PLAN_MAX_ARGS = 24                       # include/mi355det_plan.h
-PLAN_MAIN, PLAN_SIDE, PLAN_SIDE_RR = 0, 1, 2
+PLAN_MAIN, PLAN_SIDE, PLAN_SIDE_RR, PLAN_JOIN = 0, 1, 2, 3
 
 
 class PlanStep(ctypes.Structure):
@@ -274,6 +274,10 @@ class RetinaPlan(object):
         if getattr(self, '_mark_side', False):
             self._side_ids.add(id(args))
 
+    def _join_step(self, lst):
+        """A join edge inside a launch list: the main stream waits for what the list has sent to the side stream so far."""
+        lst.append((None, (), 'join:'))
+
     SIDE_STEPS = ('mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_slabs_f32', 'mi355_conv_wgrad_multi')
 
     # ------------------------------------------------------------------ replay (include/mi355det_plan.h)
@@ -296,6 +300,9 @@ class RetinaPlan(object):
             st = arr[i]
             if name.startswith('py:'):                         # host-side step (BN statistics all-reduce)
                 st.host, st.fn = 1, -1
+                continue
+            if name == 'join:':                                # main waits for the side stream(s): an edge, no launch
+                st.where, st.fn = PLAN_JOIN, -1
                 continue
             if fn is None:
                 raise _lib.Mi355Error('unknown deferred step %r' % (name,))
@@ -360,6 +367,9 @@ class RetinaPlan(object):
         for i, (fn, args, name) in enumerate(steps[begin:end]):
             if name.startswith('py:'):
                 fn(stream)
+                continue
+            if name == 'join:':
+                self.join_side()
                 continue
             if _lib.TRACE_PATH:
                 _lib.trace_begin('%s[%d] %s' % (which, begin + i, name))
@@ -949,16 +959,35 @@ class RetinaPlan(object):
 
     def _stages_fwd(self, x):
         feats = []
+        # The downsample conv of a stage's first block (utils_resnet.py:72-73) only depends on the block input: it runs on
+        # the side stream - idle in the forward until the box head - beside conv1 / conv2, and the join edge in front of
+        # the conv that adds it as the residual orders main behind it (MI355_DS_SIDE=0: in line).  Frozen BN only: the
+        # statistics passes of a train-mode BN would pull the whole chain over.
+        ds_side = os.environ.get('MI355_DS_SIDE', '1') == '1' and self.use_side and not self._mark_side
+
+        def downsample(rec, x):
+            if rec['ds'] is None:
+                return x, False
+            side = ds_side and not rec['ds'].bn_train
+            first = len(self.fwd_steps)
+            res = self.conv(rec['ds'], x)
+            if side:
+                for st in self.fwd_steps[first:]:
+                    self._side_ids.add(id(st[1]))
+            return res, side
         for rec in self.blocks:
             rec['x'] = x
+            res, joined = downsample(rec, x)
             if rec['kind'] == 'bottleneck':
                 rec['a'] = self.conv(rec['c1'], x, ACT_RELU)
                 rec['b'] = self.conv(rec['c2'], rec['a'], ACT_RELU)
-                res = self.conv(rec['ds'], x) if rec['ds'] is not None else x
+                if joined:
+                    self._join_step(self.fwd_steps)
                 rec['out'] = self.conv(rec['c3'], rec['b'], ACT_RELU, addend=res)
             else:
                 rec['a'] = self.conv(rec['c1'], x, ACT_RELU)
-                res = self.conv(rec['ds'], x) if rec['ds'] is not None else x
+                if joined:
+                    self._join_step(self.fwd_steps)
                 rec['out'] = self.conv(rec['c2'], rec['a'], ACT_RELU, addend=res)
             x = rec['out']
             if rec['stage_end']:
@@ -970,15 +999,31 @@ class RetinaPlan(object):
         c3, c4, c5 = feats[1], feats[2], feats[3]
         self.c3, self.c4, self.c5 = c3, c4, c5
         f = self.fpn
+        # P6 = conv(C5) -> ReLU -> P7 only depends on C5: three short launches (split-K convs over 8^2 / 4^2 maps) that
+        # run on the side stream beside the laterals and the smoothing convs; the join edge in front of the heads orders
+        # main behind them (MI355_FPN_SIDE=0: in line, after the smoothing convs as before)
+        side_branch = os.environ.get('MI355_FPN_SIDE', '1') == '1' and self.use_side and not self._mark_side
+
+        def extra_levels():
+            first = len(self.fwd_steps)
+            self.p6 = self.conv(f['P6'], c5)
+            self.p6relu = self.new(tuple(self.p6.shape))
+            self._step(self.fwd_steps, 'mi355_relu_mask_bf16', ptr(self.p6), ptr(self.p6), ptr(self.p6relu),
+                       c_i64(self.p6.numel()))
+            self.p7 = self.conv(f['P7_2'], self.p6relu)
+            if side_branch:
+                for st in self.fwd_steps[first:]:
+                    self._side_ids.add(id(st[1]))
+        if side_branch:
+            extra_levels()
         self.p5lat = self.conv(f['P5_1'], c5)
         self.p4lat = self.conv(f['P4_1'], c4, addend=self.p5lat, add_shift=1)
         self.p3lat = self.conv(f['P3_1'], c3, addend=self.p4lat, add_shift=1)
         self.p3, self.p4, self.p5 = self.conv_group([f['P3_2'], f['P4_2'], f['P5_2']], [self.p3lat, self.p4lat, self.p5lat])
-        self.p6 = self.conv(f['P6'], c5)
-        self.p6relu = self.new(tuple(self.p6.shape))
-        self._step(self.fwd_steps, 'mi355_relu_mask_bf16', ptr(self.p6), ptr(self.p6), ptr(self.p6relu),
-                   c_i64(self.p6.numel()))
-        self.p7 = self.conv(f['P7_2'], self.p6relu)
+        if side_branch:
+            self._join_step(self.fwd_steps)
+        else:
+            extra_levels()
         self.levels = [self.p3, self.p4, self.p5, self.p6, self.p7]
 
     def _heads_fwd(self):

@@ -22,7 +22,7 @@ rows = []
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for phase in ('fwd_steps', 'bwd_steps'):
     for idx, (fn, args, name) in enumerate(getattr(plan, phase)):
-        if name.startswith('py:') or name.startswith('__'):
+        if name.startswith(('py:', '__', 'join:')):
             continue
         if name in bench.CONV_STEPS:
             L = args[0]._obj
