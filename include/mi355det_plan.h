@@ -25,6 +25,10 @@ extern "C" {
 #define MI355_PLAN_SIDE_RR 2 /* as SIDE, alternating between side and side2 when side2 is given */
 #define MI355_PLAN_JOIN 3   /* no launch (fn is ignored): main waits for everything issued to the side stream(s) so far -
                                a join edge inside a list, e.g. behind a short independent branch that ran on the side stream */
+#define MI355_PLAN_SIDE2 4  /* the second side stream (`side2`; `side`, then main, when it is not given): a short branch
+                               of the main chain that runs beside it while `side` carries the weight gradients */
+#define MI355_PLAN_JOIN2 5  /* no launch: main waits for `side2` only (for everything on the side streams when there is
+                               no side2) */
 
 typedef struct Mi355PlanStep {
     int32_t fn;        /* index from mi355_plan_lookup(name); the entry point's last parameter is the stream */

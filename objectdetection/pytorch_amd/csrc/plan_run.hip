@@ -114,10 +114,19 @@ extern "C" int mi355_plan_run(const Mi355PlanStep* steps, int begin, int end, vo
     for (int i = begin; i < end; ++i) {
         const Mi355PlanStep& p = steps[i];
         if (p.host) { st->next = i; return 1; }
-        if (p.where == MI355_PLAN_JOIN) {                  // a join edge inside the list (side2 -> side -> main)
-            if (side_stream) {
+        if (p.where == MI355_PLAN_JOIN || (p.where == MI355_PLAN_JOIN2 && !side2_stream)) {
+            if (side_stream) {                             // a join edge inside the list (side2 -> side -> main)
                 const int rc = mi355_plan_join(main_stream, side_stream, side2_stream, st, 0);
                 if (rc) { st->failed = i; return rc; }
+                moved[0] = moved[1] = true;
+            }
+            continue;
+        }
+        if (p.where == MI355_PLAN_JOIN2) {                 // main waits for the branch stream only
+            if (st->side2_dirty) {
+                const int rc = edge((hipStream_t)side2_stream, (hipStream_t)main_stream, "plan_run: join2");
+                if (rc) { st->failed = i; return rc; }
+                st->side2_dirty = 0;
                 moved[0] = moved[1] = true;
             }
             continue;
@@ -130,6 +139,7 @@ extern "C" int mi355_plan_run(const Mi355PlanStep* steps, int begin, int end, vo
         if (side_stream && p.where != MI355_PLAN_MAIN) {
             int which = 0;
             if (p.where == MI355_PLAN_SIDE_RR && side2_stream) which = (st->rr++) & 1;
+            if (p.where == MI355_PLAN_SIDE2 && side2_stream) which = 1;
             target = which ? side2_stream : side_stream;
             if (moved[which]) {
                 const int rc = edge((hipStream_t)main_stream, (hipStream_t)target, "plan_run: fork");

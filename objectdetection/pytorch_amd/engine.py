@@ -35,7 +35,7 @@ def _ceil8(v):
 
 # ---------------------------------------------------------------------------------------------- plan tables
 PLAN_MAX_ARGS = 24                       # include/mi355det_plan.h
-PLAN_MAIN, PLAN_SIDE, PLAN_SIDE_RR, PLAN_JOIN = 0, 1, 2, 3
+PLAN_MAIN, PLAN_SIDE, PLAN_SIDE_RR, PLAN_JOIN, PLAN_SIDE2, PLAN_JOIN2 = 0, 1, 2, 3, 4, 5
 
 
 class PlanStep(ctypes.Structure):
@@ -183,6 +183,10 @@ class RetinaPlan(object):
         self._side, self._side2 = None, None
         self._pstate = PlanState()
         self._side_ids, self._mark_side = set(), False
+        # a THIRD stream for short branches of the backward chain (the data gradient of a stage's downsample conv): they
+        # run beside the main chain while the side stream carries the weight gradients (MI355_BRANCH_STREAM=0: in line)
+        self._branch_ids = set()
+        self.use_branch = os.environ.get('MI355_BRANCH_STREAM', '1') == '1'
         self.last_arena = 0
         # one forward, one backward: the activations / assignment state of the LAST forward live in this plan's
         # buffers; `forward_serial` lets a backward detect that another forward overwrote them (retinanet._TrainStep)
@@ -274,9 +278,10 @@ class RetinaPlan(object):
         if getattr(self, '_mark_side', False):
             self._side_ids.add(id(args))
 
-    def _join_step(self, lst):
-        """A join edge inside a launch list: the main stream waits for what the list has sent to the side stream so far."""
-        lst.append((None, (), 'join:'))
+    def _join_step(self, lst, branch=False):
+        """A join edge inside a launch list: the main stream waits for what the list has sent to the side stream so far
+        (branch=True: to the branch stream only)."""
+        lst.append((None, (), 'join2:' if branch else 'join:'))
 
     SIDE_STEPS = ('mi355_conv_wgrad_slabs', 'mi355_conv_wgrad_colsum', 'mi355_conv_wgrad_slabs_f32', 'mi355_conv_wgrad_multi')
 
@@ -301,8 +306,8 @@ class RetinaPlan(object):
             if name.startswith('py:'):                         # host-side step (BN statistics all-reduce)
                 st.host, st.fn = 1, -1
                 continue
-            if name == 'join:':                                # main waits for the side stream(s): an edge, no launch
-                st.where, st.fn = PLAN_JOIN, -1
+            if name in ('join:', 'join2:'):                    # main waits for the side stream(s) / the branch stream
+                st.where, st.fn = (PLAN_JOIN if name == 'join:' else PLAN_JOIN2), -1
                 continue
             if fn is None:
                 raise _lib.Mi355Error('unknown deferred step %r' % (name,))
@@ -316,6 +321,8 @@ class RetinaPlan(object):
                 st.where = PLAN_SIDE_RR if self.n_side > 1 else PLAN_SIDE
             elif id(args) in self._side_ids:
                 st.where = PLAN_SIDE
+            elif id(args) in self._branch_ids:
+                st.where = PLAN_SIDE2
             for j, a in enumerate(args):
                 st.arg[j] = _slot(a)
         ent = (arr, n, [i for i in range(n) if arr[i].host], steps)
@@ -339,7 +346,7 @@ class RetinaPlan(object):
         side = side2 = None
         if self._side_active():
             side = self._side_stream().cuda_stream
-            if self.n_side > 1:
+            if self.n_side > 1 or (self.use_branch and self._branch_ids):
                 if self._side2 is None:
                     self._side2 = torch.cuda.Stream(device=self.dev)
                 side2 = self._side2.cuda_stream
@@ -370,6 +377,8 @@ class RetinaPlan(object):
                 continue
             if name == 'join:':
                 self.join_side()
+                continue
+            if name == 'join2:':                               # (branch steps run in line in this mode)
                 continue
             if _lib.TRACE_PATH:
                 _lib.trace_begin('%s[%d] %s' % (which, begin + i, name))
@@ -961,9 +970,10 @@ class RetinaPlan(object):
         feats = []
         # The downsample conv of a stage's first block (utils_resnet.py:72-73) only depends on the block input: it runs on
         # the side stream - idle in the forward until the box head - beside conv1 / conv2, and the join edge in front of
-        # the conv that adds it as the residual orders main behind it (MI355_DS_SIDE=0: in line).  Frozen BN only: the
+        # the conv that adds it as the residual orders main behind it.  MI355_DS_SIDE=1 (off by default: measured within +-0.3 %
+        # of the in-line order at 512^2 and 640^2 - the side stream's launch only moves bytes the chain waits for anyway).  Frozen BN only: the
         # statistics passes of a train-mode BN would pull the whole chain over.
-        ds_side = os.environ.get('MI355_DS_SIDE', '1') == '1' and self.use_side and not self._mark_side
+        ds_side = os.environ.get('MI355_DS_SIDE', '0') == '1' and self.use_side and not self._mark_side
 
         def downsample(rec, x):
             if rec['ds'] is None:
@@ -1153,6 +1163,18 @@ class RetinaPlan(object):
                 x_extra = extra[self.blocks[i - 1]['stage']]
             # x = max-pool output for the very first block (its ReLU mask is applied by the pool backward)
             mask_x = None if (first_block and self.has_maxpool) else x
+            # the data gradient of the downsample conv (79 - 95 us at R50 512^2: a 1x1 / stride-2 conv = four parity
+            # classes) only meets the conv3 -> conv2 -> conv1 chain of its block at the final add: it is issued first and
+            # runs on the branch stream beside that chain; main joins it in front of conv1's data gradient
+            branch = (rec['ds'] is not None and self.use_branch and self.use_side and self.n_side == 1 and
+                      not rec['ds'].bn_train)
+            res_g = None
+            if branch:
+                first = len(self.bwd_steps)
+                res_g = self.conv_bwd(rec['ds'], x, g, dx=x_extra, addend=x_extra)
+                for st in self.bwd_steps[first:]:
+                    if st[2] == 'mi355_conv_gather':
+                        self._branch_ids.add(id(st[1]))
             if rec['kind'] == 'bottleneck':
                 g_b = self.conv_bwd(rec['c3'], rec['b'], g, mask=rec['b'])
                 g_a = self.conv_bwd(rec['c2'], rec['a'], g_b, mask=rec['a'])
@@ -1160,7 +1182,9 @@ class RetinaPlan(object):
             else:
                 g_a = self.conv_bwd(rec['c2'], rec['a'], g, mask=rec['a'])
                 last = rec['c1']
-            if rec['ds'] is not None:
+            if branch:
+                self._join_step(self.bwd_steps, branch=True)
+            elif rec['ds'] is not None:
                 res_g = self.conv_bwd(rec['ds'], x, g, dx=x_extra, addend=x_extra)
             else:
                 assert x_extra is None
