@@ -162,7 +162,9 @@ extern "C" int mi355_plan_join(void* main_stream, void* side_stream, void* side2
     if (st->side2_dirty && side2_stream && side_stream) {
         const int rc = edge((hipStream_t)side2_stream, (hipStream_t)side_stream, "plan_join: side2 -> side");
         if (rc) return rc;
-        st->side2_dirty = 0;
+        // (a fold leaves side2 marked: main has not waited for it, and a MI355_PLAN_JOIN2 step of a later run - the
+        //  backward is replayed range by range - must still issue its side2 -> main edge)
+        if (!fold_only) st->side2_dirty = 0;
         st->side_dirty = 1;
     }
     if (fold_only) return MI355_OK;

@@ -1137,9 +1137,19 @@ class RetinaPlan(object):
         # RetinaNet: the heads read the raw P6 (retinanet.py:64-67, P7_1 = nn.ReLU() out of place): only the P7 branch
         # passes the ReLU mask.  KSevenDet's `F.relu(P6, inplace=True)` (neck/fpn.py:286) rectifies the tensor that is
         # ALSO handed to the heads: head gradient and P7 gradient are masked together (mask after the addend).
+        # The P7 -> P6 -> C5 data gradients (short split-K launches over 4^2 / 8^2 / 16^2 maps) only meet the rest of the
+        # pyramid's backward at C5: they run on the branch stream beside the smoothing / lateral gradients.  Their weight
+        # gradients are deferred to the end of the pyramid (grouping on), i.e. behind the join: P6's reads g_p6.
+        branch = (self.use_branch and self.use_side and self.n_side == 1 and self._grouping_wgrads and
+                  os.environ.get('MI355_FPN_BRANCH', '1') == '1')
+        first = len(self.bwd_steps)
         self.conv_bwd(f['P7_2'], self.p6relu, g_p7, dx=g_p6, addend=g_p6, mask=self.p6,
                       mask_first=not getattr(self, 'p6_relu_inplace', False))
         g_c5 = self.conv_bwd(f['P6'], self.c5, g_p6)
+        if branch:
+            assert all(st[2] not in self.SIDE_STEPS for st in self.bwd_steps[first:]), 'weight gradients were to be deferred'
+            for st in self.bwd_steps[first:]:
+                self._branch_ids.add(id(st[1]))
         g_p3lat, g_p4lat, g_p5lat = self.conv_bwd_group([f['P3_2'], f['P4_2'], f['P5_2']],
                                                         [self.p3lat, self.p4lat, self.p5lat], [g_p3, g_p4, g_p5])
         self._sumpool(g_p3lat, g_p4lat)
@@ -1147,6 +1157,8 @@ class RetinaPlan(object):
         self._sumpool(g_p4lat, g_p5lat)
         g_c4 = self.conv_bwd(f['P4_1'], self.c4, g_p4lat)
         # c5 has no later consumer: finish it here (sum of P6 and P5_1 grads, ReLU of layer4)
+        if branch:
+            self._join_step(self.bwd_steps, branch=True)
         self.conv_bwd(f['P5_1'], self.c5, g_p5lat, dx=g_c5, addend=g_c5, mask=self.c5)
         return g_c5, {2: g_c4, 1: g_c3}            # raw FPN-lateral grads of the stage outputs
 

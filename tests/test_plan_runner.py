@@ -57,8 +57,11 @@ def _table(lib, rows):
     for st, (kind, n) in zip(arr, rows):
         if kind == 'host':
             st.host, st.fn = 1, -1
+        elif kind in ('join', 'join2'):                     # edges inside a list: no launch, fn is ignored
+            st.fn, st.where = -1, (engine.PLAN_JOIN if kind == 'join' else engine.PLAN_JOIN2)
         else:
-            st.fn, st.nargs, st.where = zr, 3, (1 if kind == 'side' else 0)
+            st.fn, st.nargs = zr, 3
+            st.where = {'side': engine.PLAN_SIDE, 'side2': engine.PLAN_SIDE2}.get(kind, engine.PLAN_MAIN)
             st.arg[0], st.arg[1], st.arg[2] = 0, n & ((1 << 64) - 1), 1
     return arr
 
@@ -84,5 +87,9 @@ def test_run_protocol_without_a_gpu():
     bad[0].nargs = 2                           # arity mismatch is caught before the call
     assert run(bad, ctypes.c_int(0), ctypes.c_int(1), vp(None), vp(None), vp(None), ctypes.byref(state)) == -1
     assert state.failed == 0
+    # join edges and branch-stream steps degrade to the main stream when the run has no side streams
+    tab2 = _table(lib, [('main', 0), ('side2', 0), ('join2', 0), ('side', 0), ('join', 0), ('main', 0)])
+    assert run(tab2, ctypes.c_int(0), ctypes.c_int(6), vp(None), vp(None), vp(None), ctypes.byref(state)) == 0
+    assert state.side_dirty == 0 and state.side2_dirty == 0 and state.forks == 0
     # join with nothing dirty is a no-op without a GPU
     assert lib.mi355_plan_join(vp(None), vp(None), vp(None), ctypes.byref(state), ctypes.c_int(0)) == 0
