@@ -1165,9 +1165,10 @@ class RetinaPlan(object):
     def _stages_bwd(self, g, extra):
         """Backbone, last block first.  g = gradient w.r.t. the block output's pre-ReLU sum."""
         group = self._wgrad_grouping_ok()
+        group_l1 = os.environ.get('MI355_WG_GROUP_L1', '1') == '1'     # (A/B: layer1's weight gradients issued block by block)
         for i in range(len(self.blocks) - 1, -1, -1):
             rec = self.blocks[i]
-            self._grouping_wgrads = group
+            self._grouping_wgrads = group and (group_l1 or rec['stage'] != 0)
             x = rec['x']
             first_block = (i == 0)
             x_extra = None
@@ -1491,13 +1492,33 @@ class RetinaPlan(object):
         self._run(steps, st, self._bwd_pos, seg[0])
         self._bwd_pos = seg[0]
         self._fold_side2()
+        self._table_stream = None
         if self._side_active() and self._side_dirty:
-            self._run_param_grads(arena, self._side.cuda_stream, (seg[1], seg[2]))
+            # The side stream is the critical path of the backward (tools/side_balance.py: it finishes 0.55 ms behind
+            # main at R50 512^2), and a range's table - HBM-bound, 80 - 150 us - only needs that range's weight
+            # gradients.  MI355_TABLE_STREAM=1 sends it to the branch stream behind an edge from the side stream, beside
+            # the weight gradients of the layers still to come.  Measured and OFF: the side stream finished at the same
+            # 6.31 ms (the weight gradients slow down by what the table takes from them) and the step lost 0.7 %: the
+            # backward is throughput-bound, only short latency-bound launches gain from another stream.
+            if (self.use_branch and self.n_side == 1 and not torch.cuda.is_current_stream_capturing() and
+                    os.environ.get('MI355_TABLE_STREAM', '0') == '1'):
+                if self._side2 is None:
+                    self._side2 = torch.cuda.Stream(device=self.dev)
+                rc = self.lib.mi355_stream_fork(c_vp(self._side.cuda_stream), c_vp(self._side2.cuda_stream))
+                if rc:
+                    raise _lib.Mi355Error('stream_fork: %s' % self.lib.mi355_last_error().decode())
+                self._run_param_grads(arena, self._side2.cuda_stream, (seg[1], seg[2]))
+                self._pstate.side2_dirty = 1
+                self._table_stream = self._side2
+            else:
+                self._run_param_grads(arena, self._side.cuda_stream, (seg[1], seg[2]))
         else:
             self._run_param_grads(arena, st, (seg[1], seg[2]))
 
     def exchange_stream(self):
         """Stream on which the gradients of the last finished range are complete."""
+        if getattr(self, '_table_stream', None) is not None:
+            return self._table_stream
         if self._side_active() and self._side_dirty:
             return self._side
         return torch.cuda.current_stream(self.dev)
