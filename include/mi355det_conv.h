@@ -59,6 +59,12 @@ typedef struct Mi355ConvLaunch {
     const float* bias;    /* optional fp32 [K] (conv bias or folded frozen-BN shift) */
     int32_t out_f32;      /* 0: bf16 out, 1: fp32 out */
     int32_t flags;        /* bit 0: apply the mask BEFORE the addend: act(acc*mask + addend) */
+    float* stats;         /* optional (mi355_conv_gather, one problem, bf16 out, no addend, K % 8 == 0): per-tile column
+                             statistics of the STORED output for a train-mode BatchNorm behind the conv
+                             (utils/sync_batchnorm/batchnorm.py:63-93: sum and square-sum per channel), fp32
+                             [ceil(M / 128)][2][K] = the partial-sum layout of mi355_bn_nhwc_stats with one block per
+                             128-row tile, so mi355_bn_nhwc_reduce(stats, ceil(M / 128), K, ...) finishes them: the
+                             statistics pass over z disappears */
 } Mi355ConvLaunch;
 
 /* out = act( gatherconv(in, weight) + bias + addend ) * (mask > 0) for every problem. */

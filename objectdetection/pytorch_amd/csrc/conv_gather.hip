@@ -55,6 +55,7 @@ struct LaunchDev {
     int nprob, K, T, act, out_f32, n_tiles, w_bytes, flags;
     int ksplit, tiles_total;      // split-K: blockIdx = split * tiles_total + tile
     long long split_stride;       // floats between the partial-output slabs of consecutive splits
+    float* stats;                 // per-tile column statistics of the stored output (Mi355ConvLaunch.stats) or null
 };
 
 __device__ __forceinline__ float activate(float v, int act) {
@@ -102,10 +103,13 @@ __device__ __forceinline__ void init_acc(f4v (&acc)[TA][4], const LaunchDev& L, 
 // 16-B coalesced row stores.
 // TA = 16-row accumulator fragments per wave: 4 (64x64 per wave, 2 wave columns, 128-wide tile) or 2
 // (32x64 per wave, 4 wave rows, 64-wide tile: K <= 64 layers without empty wave columns).
-template <int WM, int TA = 4>
+// ST: the launch also leaves per-tile column statistics of its output (Mi355ConvLaunch.stats).  A template parameter, not a
+// run-time branch: with the branch compiled in, the narrow generic kernel needs 103 instead of 94 VGPRs and loses its fifth
+// block per CU (-2 % on the frozen-BN R50 step, A/B of two builds in one call).
+template <int WM, int TA = 4, bool ST = false>
 __device__ __forceinline__ void gather_epilogue(f4v (&acc)[TA][4], const LaunchDev& L, const ProbDev& P,
                                                 unsigned char* smem, const long long* s_outoff,
-                                                const long long* s_addoff, int n0) {
+                                                const long long* s_addoff, int n0, int m_tile) {
     constexpr int NTHREADS = WM * 128, BM = WM * 64, BNT = TA == 4 ? 128 : 64;
     constexpr int CT = BNT / 8, RP = NTHREADS / CT;    // threads per output row, rows per read pass
     constexpr int LD16 = BNT + 4, LD32 = BNT + 4;
@@ -155,6 +159,42 @@ __device__ __forceinline__ void gather_epilogue(f4v (&acc)[TA][4], const LaunchD
                     o[e] = ((unsigned short)mk[pass][e] & 0x8000u) || !((unsigned short)mk[pass][e] & 0x7fffu) ? (short)0 : o[e];
             }
             *reinterpret_cast<s8v*>(reinterpret_cast<unsigned short*>(P.out) + oo[pass] + k0) = o;
+        }
+        if constexpr (ST) {
+            // Column statistics of the tile for a train-mode BatchNorm behind this conv: sum and square-sum of the
+            // STORED (bf16-rounded) values, rows past M left out; a thread adds its rows in row order, the RP row threads
+            // of a column are added in thread order by one thread per column: a fixed order (bit-reproducible).
+            float fs[8], fq[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { fs[e] = 0.0f; fq[e] = 0.0f; }
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                if (oo[pass] < 0) continue;
+                const int row = pass * RP + tid / CT;
+                const s4v lo = *reinterpret_cast<const s4v*>(st16 + row * LD16 + col);
+                const s4v hi = *reinterpret_cast<const s4v*>(st16 + row * LD16 + col + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = bf16_to_f32((unsigned short)lo[e]), b = bf16_to_f32((unsigned short)hi[e]);
+                    fs[e] += a; fq[e] += a * a; fs[e + 4] += b; fq[e + 4] += b * b;
+                }
+            }
+            __syncthreads();                                   // the staged tile has been read out
+            float* red = reinterpret_cast<float*>(smem);       // [RP][2][BNT]
+            const int rt = tid / CT;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(rt * 2 + 0) * BNT + col + e] = fs[e];
+                red[(rt * 2 + 1) * BNT + col + e] = fq[e];
+            }
+            __syncthreads();
+            for (int t = tid; t < 2 * BNT; t += NTHREADS) {
+                const int which = t / BNT, c = t - which * BNT;
+                if (n0 + c >= L.K) continue;
+                float a = 0.0f;
+                for (int r = 0; r < RP; ++r) a += red[(r * 2 + which) * BNT + c];
+                L.stats[((long long)m_tile * 2 + which) * L.K + n0 + c] = a;
+            }
         }
         return;
     }
@@ -242,7 +282,7 @@ __device__ __forceinline__ void gather_epilogue(f4v (&acc)[TA][4], const LaunchD
 //                   CU): everything else - HBM-bound 1x1 convs, layers with K <= 64, small launches.
 // (Measured and dropped this round: a 256x128 tile with a 3-stage counted-vmcnt ring at one block per CU and
 //  a 4-stage 128x128 ring - both slower than more resident blocks.)
-template <bool FLAT, int STAGES, int WM, int TA = 4>
+template <bool FLAT, int STAGES, int WM, int TA = 4, bool ST = false>
 __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(const LaunchDev L) {
     static_assert(TA == 4 || WM == 2, "narrow tile: 4 waves");
     constexpr int NTHREADS = WM * 128, BM = WM * 64, BNT = TA == 4 ? 128 : 64;
@@ -420,7 +460,7 @@ __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(
         }
     }
 
-    gather_epilogue<WM, TA>(acc, L, P, smem, s_outoff, s_addoff, n0);
+    gather_epilogue<WM, TA, ST>(acc, L, P, smem, s_outoff, s_addoff, n0, m0 / BM);
 }
 
 
@@ -442,6 +482,7 @@ __device__ __forceinline__ s8v lds_b128(unsigned addr) {
     return v;
 }
 
+template <bool ST = false>
 __global__ __launch_bounds__(256, 2) void conv_gather_ring_kernel(const LaunchDev L) {
     constexpr int NTHREADS = 256, BM = 128, BNT = 64, TA = 2, RS = 3;
     constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = A_BYTES + BNT * BK * 2;      // 24 KiB
@@ -570,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_ring_kernel(const LaunchDe
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[sub][j], af[sub][i], acc[i][j], 0, 0, 0);
     }
     __syncthreads();                                        // every wave is done with the ring: the epilogue reuses it
-    gather_epilogue<2, TA>(acc, L, P, smem, s_outoff, s_addoff, n0);
+    gather_epilogue<2, TA, ST>(acc, L, P, smem, s_outoff, s_addoff, n0, m0 / BM);
 }
 
 
@@ -585,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_ring_kernel(const LaunchDe
 // "virtual output pixel" m0 - 1 + j; output row i and column tap s read staged row i + s.
 // STAGES = 1: one activation buffer + one weight buffer (33 KiB): three blocks per CU, the DMA latency is
 // hidden by the resident waves instead of a second stage (as in the generic one-stage kernel).
-template <int WM, int STAGES = 2, int TA = 4>
+template <int WM, int STAGES = 2, int TA = 4, bool ST = false>
 __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : (STAGES == 1 ? 3 : 2)) void conv_gather_row3_kernel(const LaunchDev L) {
     static_assert(TA == 4 || WM == 2, "narrow tile: 4 waves");
     constexpr int NTHREADS = WM * 128, BM = WM * 64, BNT = TA == 4 ? 128 : 64;
@@ -759,7 +800,7 @@ __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : (STAGES == 1 ? 3 : 2)) void
         abuf ^= 1;
     }
     __syncthreads();
-    gather_epilogue<WM, TA>(acc, L, P, smem, s_outoff, s_addoff, n0);
+    gather_epilogue<WM, TA, ST>(acc, L, P, smem, s_outoff, s_addoff, n0, m0 / BM);
 }
 
 // Split-K finish: out = mask( act( sum_s ws[s] + bias (+ addend) ) ) with the generic epilogue's ordering;
@@ -1004,7 +1045,12 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     // ---- streaming form of the short-reduction 1x1 convs (MI355_PW_STREAM: 0 off, 1 where it was measured ahead of the
     //      tiled kernels, 2 wherever it applies)
     const char* pw_env = getenv("MI355_PW_STREAM");         // (read per call: the tests switch it)
-    const int pw_mode = pw_env ? atoi(pw_env) : 1;
+    int pw_mode = pw_env ? atoi(pw_env) : 1;
+    if (in.stats) {
+        MI355_REQUIRE(in.nprob == 1 && ksplit == 1 && !in.out_f32 && !in.prob[0].addend && in.K % 8 == 0 && !in.prob[0].mask,
+                      "conv_gather: epilogue statistics need one problem, bf16 output, no addend / mask, K %% 8 == 0, no split-K");
+        pw_mode = 0;                                        // (the streaming forms have their own epilogue)
+    }
     if (pw_mode > 0 && in.nprob == 1 && ksplit == 1 && in.T > 1 && !in.out_f32 && in.K % 8 == 0 && C <= 32) {
         // window form: the space-to-depth stem (4 x 4 taps over 16 channels, stride 1): 79 -> 68 us at 16 x 256 x 256 (two
         // pixel rows per wave instead of one: 81 us, the registers cost a wave per SIMD)
@@ -1187,6 +1233,7 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     L.w = (const unsigned short*)in.weight;
     L.bias = in.bias;
     L.nprob = in.nprob; L.K = in.K; L.T = in.T; L.act = in.act; L.out_f32 = in.out_f32; L.flags = in.flags;
+    L.stats = in.stats;
     L.n_tiles = (int)cdiv(in.K, narrow ? 64 : BN);
     L.w_bytes = (int)w_bytes;
     long long grid = (long long)tiles * L.n_tiles;
@@ -1230,6 +1277,38 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     hipStream_t st = (hipStream_t)stream;
     // three-stage ring for the narrow-tile launches that are too small for residency to hide the DMA latency
     static const int ring_mode = [] { const char* e = getenv("MI355_RING"); return e ? atoi(e) : 1; }();
+    if (L.stats) {
+        // The statistics forms (ST: separate instantiations, so that the plain kernels keep their registers): non-flat
+        // reductions only, the same tile / stage choice as the plain launch would get.
+        MI355_REQUIRE(!flat, "conv_gather: epilogue statistics need C %% 64 == 0");
+        constexpr int ROW3N_B = 64 * BK * 2;
+        static bool st_attr = false;
+        if (!st_attr) {
+            (void)hipFuncSetAttribute((const void*)conv_gather_row3_kernel<2, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ROW3_A + 2 * ROW3N_B);
+            (void)hipFuncSetAttribute((const void*)conv_gather_row3_kernel<2, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ROW3_A + 2 * ROW3_B);
+            (void)hipFuncSetAttribute((const void*)conv_gather_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * NST);
+            (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NST);
+            (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);
+            st_attr = true;
+        }
+        if (narrow && row3) {
+            if (many) hipLaunchKernelGGL((conv_gather_row3_kernel<2, 1, 2, true>), g, b256, ROW3_A + ROW3N_B, st, L);
+            else      hipLaunchKernelGGL((conv_gather_row3_kernel<2, 2, 2, true>), g, b256, 2 * ROW3_A + 2 * ROW3N_B, st, L);
+        } else if (narrow && !single && ring_mode && max_ksteps >= 4) {
+            hipLaunchKernelGGL(conv_gather_ring_kernel<true>, g, b256, 3 * NST, st, L);
+        } else if (narrow) {
+            if (single) hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2, 2, true>), g, b256, NST, st, L);
+            else        hipLaunchKernelGGL((conv_gather_kernel<false, 2, 2, 2, true>), g, b256, 2 * NST, st, L);
+        } else if (row3) {
+            if (many) hipLaunchKernelGGL((conv_gather_row3_kernel<2, 1, 4, true>), g, b256, ROW3_A + ROW3_B, st, L);
+            else      hipLaunchKernelGGL((conv_gather_row3_kernel<2, 2, 4, true>), g, b256, 2 * ROW3_A + 2 * ROW3_B, st, L);
+        } else if (single) {
+            hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2, 4, true>), g, b256, EPI_BYTES, st, L);
+        } else {
+            hipLaunchKernelGGL((conv_gather_kernel<false, 2, 2, 4, true>), g, b256, 2 * STAGE2, st, L);
+        }
+        return check_launch("conv_gather_kernel<statistics>");
+    }
     if (narrow && row3) {
         constexpr int ROW3N_B = 64 * BK * 2;
         if (many) hipLaunchKernelGGL((conv_gather_row3_kernel<2, 1, 2>), g, b256, ROW3_A + ROW3N_B, st, L);
@@ -1239,10 +1318,10 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     if (narrow && !single && !flat && ring_mode && max_ksteps >= 4) {
         static bool ring_attr = false;
         if (!ring_attr) {
-            (void)hipFuncSetAttribute((const void*)conv_gather_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * NST);
+            (void)hipFuncSetAttribute((const void*)conv_gather_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * NST);
             ring_attr = true;
         }
-        hipLaunchKernelGGL(conv_gather_ring_kernel, g, b256, 3 * NST, st, L);
+        hipLaunchKernelGGL(conv_gather_ring_kernel<false>, g, b256, 3 * NST, st, L);
         return check_launch("conv_gather_ring_kernel");
     }
     if (narrow) {

@@ -617,15 +617,18 @@ class RetinaPlan(object):
         self._step(self.prep_steps, 'mi355_prep_weights_table', ptr(self.prep_table), c_int(len(descs)), c_int(nb))
 
     # ------------------------------------------------------------------ launch builders
-    def _gather(self, lst, problems, weight, K, T, bias=None, act=ACT_NONE, out_f32=False, flags=0):
+    def _gather(self, lst, problems, weight, K, T, bias=None, act=ACT_NONE, out_f32=False, flags=0, stats=None):
+        """stats: fp32 [ceil(M / 128)][2][K] - the launch also leaves the per-tile column statistics of its output there
+        (Mi355ConvLaunch.stats: one problem, bf16 output, no split-K)."""
         assert len(problems) <= ops_conv.MAX_PROBLEMS
         L = ConvLaunch()
         for j, pr in enumerate(problems):
             L.prob[j] = pr
         L.nprob, L.K, L.weight, L.T = len(problems), K, weight.data_ptr(), T
         L.act, L.bias, L.out_f32, L.flags = act, (0 if bias is None else bias.data_ptr()), int(out_f32), flags
+        L.stats = 0 if stats is None else stats.data_ptr()
         self.keep.append(L)
-        ksplit = 1 if self.prec == 'fp32' else self._pick_ksplit(problems, K, T)
+        ksplit = 1 if (self.prec == 'fp32' or stats is not None) else self._pick_ksplit(problems, K, T)
         if ksplit > 1:
             need = ksplit * sum(p.N * p.P * p.Q for p in problems) * K
             ws = self.new((need,), torch.float32)                 # partial-tile slabs of this launch
@@ -738,9 +741,17 @@ class RetinaPlan(object):
             # conv -> raw z; batch statistics; y = act(BN(z) + residual).  (K of a BN layer is a multiple of 8.)
             assert spec.Kpad == spec.K and add_shift == 0, spec.name
             pr = fwd_problem(x, out.data_ptr(), spec.R, spec.S, spec.stride, (pt, pl), K=spec.K, out_size=(P, Q))
-            self._gather(self.fwd_steps, [pr], spec.w_fwd, spec.K, spec.T, bias=spec.conv.bias)
+            # the statistics of z in the conv's own epilogue (one [sum | square-sum] row per 128-pixel tile, finished by the
+            # same reduce launch as the rows of the separate pass): one pass over z less per BN layer (MI355_BN_EPILOGUE=0)
+            tiles = None
+            # (reductions of whole 64-channel steps only: the short flat ones may take the streaming 1x1 form, whose epilogue
+            #  is its own)
+            if self.prec == 'bf16' and os.environ.get('MI355_BN_EPILOGUE', '1') == '1' and spec.Cpad % 64 == 0:
+                ntile = -(-(N * P * Q) // 128)
+                tiles = self.new((ntile, 2 * spec.K), torch.float32)
+            self._gather(self.fwd_steps, [pr], spec.w_fwd, spec.K, spec.T, bias=spec.conv.bias, stats=tiles)
             self.fwd_launches.append((spec, [(N, P, Q)]))
-            return self.bn_fwd(spec, spec.bn, out, act, addend)
+            return self.bn_fwd(spec, spec.bn, out, act, addend, tiles=tiles)
         pr = fwd_problem(x, out.data_ptr(), spec.R, spec.S, spec.stride, (pt, pl), K=spec.K,
                          addend=addend, add_shift=add_shift, out_size=(P, Q),
                          out_strides=(P * Q * spec.Kpad, Q * spec.Kpad, spec.Kpad))
@@ -865,9 +876,10 @@ class RetinaPlan(object):
         else:
             self._pystep(lst, self._bn_allreduce(buf, group), 'py:bn_allreduce')
 
-    def bn_fwd(self, spec, bn, z, act, addend, tag=None):
+    def bn_fwd(self, spec, bn, z, act, addend, tag=None, tiles=None):
         """Batch statistics of z [N,P,Q,C] -> layer state -> y = act(z*scale + shift (+ addend)).  Records what the
-        backward needs under `tag` (default: the spec) in self.bn_saved."""
+        backward needs under `tag` (default: the spec) in self.bn_saved.  tiles: the producing conv already left the
+        partial [sum | square-sum] rows there (one per 128-pixel tile): no statistics pass of its own."""
         if bn.momentum is None or not bn.affine:
             raise _lib.Mi355Error('train-mode BN in the launch plan needs affine=True and a float momentum')
         C = z.shape[-1]
@@ -883,13 +895,17 @@ class RetinaPlan(object):
         state = self.new((5 * C + (1 if counted else 0),), torch.float32)
         f32 = c_int(1 if self.prec == 'fp32' else 0)
         lst = self.fwd_steps
-        self._step(lst, 'mi355_bn_nhwc_stats', ptr(z), c_vp(0), c_vp(0), f32, c_i64(M), c_int(C), c_int(0), ptr(partials))
+        fpart, fblk = partials, nblk.value
+        if tiles is not None:
+            fpart, fblk = tiles, tiles.shape[0]
+        else:
+            self._step(lst, 'mi355_bn_nhwc_stats', ptr(z), c_vp(0), c_vp(0), f32, c_i64(M), c_int(C), c_int(0), ptr(partials))
         if counted:
-            self._step(lst, 'mi355_bn_nhwc_reduce_counted', ptr(partials), c_int(nblk.value), c_int(C), c_i64(M), ptr(sums),
+            self._step(lst, 'mi355_bn_nhwc_reduce_counted', ptr(fpart), c_int(fblk), c_int(C), c_i64(M), ptr(sums),
                        c_vp(0), c_vp(0))
             self._bn_exchange_step(lst, sums, group)
         else:
-            self._step(lst, 'mi355_bn_nhwc_reduce', ptr(partials), c_int(nblk.value), c_int(C), ptr(sums), c_vp(0), c_vp(0))
+            self._step(lst, 'mi355_bn_nhwc_reduce', ptr(fpart), c_int(fblk), c_int(C), ptr(sums), c_vp(0), c_vp(0))
         track = bn.track_running_stats and bn.running_mean is not None
         plain = type(bn) is torch.nn.BatchNorm2d            # nn.BatchNorm2d.forward counts batches; the sync class does not
         self._step(lst, 'mi355_bn_nhwc_finalize', ptr(sums), c_f32(0.0 if counted else float(M) * world), c_int(C), c_f32(bn.eps),

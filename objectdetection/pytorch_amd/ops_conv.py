@@ -29,7 +29,7 @@ class ConvProblem(ctypes.Structure):
 class ConvLaunch(ctypes.Structure):
     _fields_ = [('prob', ConvProblem * MAX_PROBLEMS), ('nprob', c_int), ('K', c_int),
                 ('weight', c_vp), ('T', c_int), ('act', c_int), ('bias', c_vp),
-                ('out_f32', c_int), ('flags', c_int)]
+                ('out_f32', c_int), ('flags', c_int), ('stats', c_vp)]
 
 
 class LayerDesc(ctypes.Structure):
@@ -119,7 +119,8 @@ def dgrad_problems(dy, dx_ptr, H, W, Cin, R, S, stride, pad, addend=None, mask=N
     return probs
 
 
-def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE, out_f32=False, ksplit=1, flags=0):
+def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE, out_f32=False, ksplit=1, flags=0,
+                  stats=None):
     f32 = weight.dtype == torch.float32            # fp32-accurate mode: every operand fp32 (conv_f32.hip)
     for i in range(0, len(problems), MAX_PROBLEMS):
         chunk = problems[i:i + MAX_PROBLEMS]
@@ -128,6 +129,7 @@ def launch_gather(problems, weight, K, T, stream_tensor, bias=None, act=ACT_NONE
             L.prob[j] = pr
         L.nprob, L.K, L.weight, L.T = len(chunk), K, weight.data_ptr(), T
         L.act, L.bias, L.out_f32, L.flags = act, _dp(bias), 1 if out_f32 else 0, flags
+        L.stats = _dp(stats)
         if f32:
             call('mi355_conv_gather_f32', ctypes.byref(L), stream_of(stream_tensor))
         elif ksplit > 1:      # reduction split over blocks, partial tiles in a scratch workspace
@@ -219,14 +221,14 @@ def pick_split_rows(total_rows, tiles_per_chunk, target_blocks=512, min_rows=512
 
 # ---------------------------------------------------------------- simple single-problem helpers
 def conv_fwd(x, w_fwd, K, R, S, stride, pad, bias=None, act=ACT_NONE, addend=None, add_shift=0,
-             out_f32=False, ksplit=1):
+             out_f32=False, ksplit=1, stats=None):
     require_gpu(x, w_fwd)
     N, H, W, C = x.shape
     P, Q = out_hw(H, W, R, stride, pad)[0], out_hw(H, W, S, stride, pad)[1]
     out = torch.empty((N, P, Q, K), dtype=torch.float32 if (out_f32 or x.dtype == torch.float32) else torch.bfloat16,
                       device=x.device)
     pr = fwd_problem(x, out.data_ptr(), R, S, stride, pad, K=K, addend=addend, add_shift=add_shift)
-    launch_gather([pr], w_fwd, K, R * S, x, bias=bias, act=act, out_f32=out_f32, ksplit=ksplit)
+    launch_gather([pr], w_fwd, K, R * S, x, bias=bias, act=act, out_f32=out_f32, ksplit=ksplit, stats=stats)
     return out
 
 

@@ -78,6 +78,41 @@ def test_conv_fwd(dev, case):
     _close(out.permute(0, 3, 1, 2), torch.sigmoid(ref), 2e-3)
 
 
+# N, H, W, C, K, R, stride, pad: narrow generic (1x1), ring (256 - 767 tiles), narrow row-of-taps, wide row-of-taps (>= 1024
+# tiles of 128 x 128), a ragged M (rows past M in the last tile) and a stride-2 conv
+STATS_CASES = [(2, 40, 40, 256, 64, 1, 1, 0), (16, 32, 32, 1024, 256, 1, 1, 0), (4, 32, 32, 128, 128, 3, 1, 1),
+               (16, 64, 64, 256, 256, 3, 1, 1), (3, 19, 23, 64, 192, 3, 1, 1), (2, 33, 31, 128, 256, 3, 2, 1)]
+
+
+@pytest.mark.parametrize('case', STATS_CASES)
+def test_conv_fwd_epilogue_statistics(dev, case):
+    """Mi355ConvLaunch.stats: the launch leaves one [sum | square-sum] row per 128-pixel tile of its STORED output (the
+    batch statistics of a train-mode BatchNorm behind the conv, utils/sync_batchnorm/batchnorm.py:63-93); the rows summed
+    over the tiles must equal the column sums of the bf16 output tensor the launch wrote (fp32 summation order only), and
+    the output itself must not change."""
+    from objectdetection.pytorch_amd import ops_conv
+    N, H, W, C, K, R, stride, pad = case
+    x = _mk((N, C, H, W), 1)
+    w = _mk((K, C, R, R), 2, scale=(2.0 / (C * R * R)) ** 0.5)
+    _, w_fwd, _ = _shadow(w, dev)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    plain = ops_conv.conv_fwd(xh, w_fwd, K, R, R, stride, pad)
+    M = plain.numel() // K
+    ntile = -(-M // 128)
+    st = torch.full((ntile, 2, K), float('nan'), device=dev)
+    out = ops_conv.conv_fwd(xh, w_fwd, K, R, R, stride, pad, stats=st)
+    assert torch.equal(out, plain)
+    z = out.double().reshape(M, K)
+    got = st.double().sum(0)
+    assert torch.isfinite(st).all()
+    np.testing.assert_allclose(got[0].cpu().numpy(), z.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4 * float(z.abs().mean()) * M ** 0.5)
+    np.testing.assert_allclose(got[1].cpu().numpy(), (z * z).sum(0).cpu().numpy(), rtol=1e-5)
+    # the rows are per tile: tile t covers output rows [128 t, 128 t + 128)
+    t = ntile // 2
+    rows = z[128 * t:128 * t + 128]
+    np.testing.assert_allclose(st[t, 1].double().cpu().numpy(), (rows * rows).sum(0).cpu().numpy(), rtol=1e-5)
+
+
 @pytest.mark.parametrize('case', [(2, 128, 128, 16, 96), (1, 96, 100, 24, 144), (2, 33, 47, 96, 16), (1, 40, 40, 144, 40),
                                   (1, 31, 29, 240, 40), (3, 17, 19, 40, 240), (1, 64, 64, 200, 24), (1, 30, 30, 256, 72),
                                   (2, 20, 20, 112, 8), (1, 25, 25, 176, 48)])
