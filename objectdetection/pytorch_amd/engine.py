@@ -278,6 +278,9 @@ class RetinaPlan(object):
         if getattr(self, '_mark_side', False):
             self._side_ids.add(id(args))
 
+    def _tail_wgrads_main(self):
+        return int(os.environ.get('MI355_TAIL_WGRADS_MAIN', '0'))
+
     def _join_step(self, lst, branch=False):
         """A join edge inside a launch list: the main stream waits for what the list has sent to the side stream so far
         (branch=True: to the branch stream only)."""
@@ -301,6 +304,14 @@ class RetinaPlan(object):
         n = len(steps)
         arr = (PlanStep * max(n, 1))()
         lookup, arity = self.lib.mi355_plan_lookup, self.lib.mi355_plan_arity
+        # MI355_TAIL_WGRADS_MAIN=n: the LAST n weight-gradient launches of a backward list stay on the main stream.  The
+        # side stream (weight gradients + tables) finishes behind main (tools/side_balance.py: 0.55 ms at R50 512^2, 0.33 ms
+        # at EfficientDet-D0), and at the end of the backward main has nothing left to run beside it.
+        keep_main = set()
+        ntail = self._tail_wgrads_main()
+        if ntail and (steps is self.bwd_steps or steps is getattr(self, 'bwd_steps_alt', None)):
+            side_idx = [i for i, st_ in enumerate(steps) if st_[2] in self.SIDE_STEPS]
+            keep_main = set(side_idx[-ntail:])
         for i, (fn, args, name) in enumerate(steps):
             st = arr[i]
             if name.startswith('py:'):                         # host-side step (BN statistics all-reduce)
@@ -317,7 +328,7 @@ class RetinaPlan(object):
             if len(args) != arity(idx):
                 raise _lib.Mi355Error('%s takes %d arguments before the stream, the step has %d' % (name, arity(idx), len(args)))
             st.fn, st.nargs = idx, len(args)
-            if name in self.SIDE_STEPS:
+            if name in self.SIDE_STEPS and i not in keep_main:
                 st.where = PLAN_SIDE_RR if self.n_side > 1 else PLAN_SIDE
             elif id(args) in self._side_ids:
                 st.where = PLAN_SIDE
@@ -1509,6 +1520,10 @@ class RetinaPlan(object):
         self._bwd_pos = seg[0]
         self._fold_side2()
         self._table_stream = None
+        if self._side_active() and self._side_dirty and self._tail_wgrads_main():
+            rc = self.lib.mi355_stream_fork(c_vp(st), c_vp(self._side.cuda_stream))   # (a table may read a slab written on main)
+            if rc:
+                raise _lib.Mi355Error('stream_fork: %s' % self.lib.mi355_last_error().decode())
         if self._side_active() and self._side_dirty:
             # The side stream is the critical path of the backward (tools/side_balance.py: it finishes 0.55 ms behind
             # main at R50 512^2), and a range's table - HBM-bound, 80 - 150 us - only needs that range's weight
