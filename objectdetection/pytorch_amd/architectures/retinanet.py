@@ -98,17 +98,17 @@ class _TrainStep(torch.autograd.Function):
         plan.run_heads(img)
         losses_ = plan.run_loss(anchors, annot)
         ctx.plan, ctx.serial = plan, plan.forward_serial
+        ctx.inputs = (anchors, img, annot, tuple(p._version for p in plan.params))
         return losses_[0:1].clone(), losses_[1:2].clone()
 
     @staticmethod
     def backward(ctx, g_cls, g_reg):
         if ctx.serial != ctx.plan.forward_serial:
-            # the reference's autograd graph keeps per-call activations; the launch plan keeps ONE set per
-            # (batch, H, W): a second forward on the same shape (validation call, return_head, a second
-            # micro-batch) before this backward overwrote what it needs
-            raise RuntimeError('mi355det: another forward ran on this launch plan (shape %dx%dx%d) between this '
-                               'loss\'s forward and its backward; call backward() before the next forward of '
-                               'the same input shape' % (ctx.plan.B, ctx.plan.H, ctx.plan.W))
+            # the reference's autograd graph keeps per-call activations; the launch plan keeps ONE set per (batch, H, W):
+            # another forward on the same shape (validation call, return_head, a second micro-batch) overwrote what this
+            # backward needs - the forward of THIS batch is re-run first (engine.RetinaPlan.restore_forward; raises where
+            # that is not possible)
+            ctx.serial = ctx.plan.restore_forward(*ctx.inputs)
         grads = ctx.plan.run_backward(g_cls, g_reg)
         return (None, None, None, None) + tuple(grads)
 

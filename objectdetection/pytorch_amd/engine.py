@@ -1421,6 +1421,30 @@ class RetinaPlan(object):
                   ptr(self.loss_ws), c_i64(self.loss_ws_bytes), c_vp(self._stream()))
         return self.losses
 
+    # ------------------------------------------------------------------ a forward overwritten before its backward
+    def restore_forward(self, anchors, img, annot, versions):
+        """The plan keeps ONE set of activations per input shape; the reference's autograd graph keeps them per call.
+        When another forward of the same shape ran between a loss and its backward (a validation / `return_head` call,
+        kseven_inference_debuger.py:310-317; a second micro-batch), the backward re-runs the forward of ITS batch first:
+        the same launches on the same inputs and weights restore the activations bit for bit.  Not possible - and raised,
+        as before - when the forward has side effects or draws: train-mode BatchNorm (running statistics), drop-connect;
+        or when a parameter was modified in place since (the reference's autograd raises there too)."""
+        why = None
+        if self.bn_saved:
+            why = 'the plan has train-mode BatchNorm layers (a second forward would move the running statistics again)'
+        elif getattr(self, 'drop_connect', False):
+            why = 'drop-connect is active (a second forward would draw other branches)'
+        elif versions != tuple(p._version for p in self.params):
+            why = 'a parameter was modified in place since that forward'
+        if why:
+            raise RuntimeError('mi355det: another forward ran on this launch plan (shape %dx%dx%d) between this '
+                               'loss\'s forward and its backward, and the forward cannot be re-run: %s; call '
+                               'backward() before the next forward of the same input shape' % (self.B, self.H, self.W, why))
+        with torch.no_grad():
+            self.run_heads(img)
+            self.run_loss(anchors, annot)
+        return self.forward_serial
+
     def _stem_dwp_ptr(self):
         return self.stem_dwp.data_ptr() if getattr(self, 'stem_s2d', False) else -1
 

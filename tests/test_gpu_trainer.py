@@ -301,24 +301,62 @@ def test_trainer_leaves_frozen_parameters_alone():
     assert float(torch.linalg.vector_norm(live)) <= 0.1 * 1.001
 
 
-def test_backward_after_second_forward_raises():
-    """The launch plan keeps ONE set of activations per input shape: a forward between a loss and its
-    backward (validation call, return_head, second micro-batch) must raise instead of silently returning
-    the gradients of the wrong batch."""
+def test_backward_after_another_forward_of_the_same_shape():
+    """The launch plan keeps ONE set of activations per input shape; the reference's autograd graph keeps them per call.
+    A forward between a loss and its backward (validation call, `return_head`: kseven_inference_debuger.py:310-317; a
+    second micro-batch) must not change the gradients: the backward re-runs the forward of its own batch first.  Where
+    that is impossible (train-mode BatchNorm: the running statistics would move twice; an optimizer step in between) it
+    raises instead of returning the gradients of the wrong batch."""
     dev = torch.device('cuda', 0)
     model = _model(dev)
     img = torch.from_numpy(synth.synth_images(2, 64, 64, seed=1)).to(dev)
     ann = torch.from_numpy(synth.synth_annotations(2, 64, 64, 4, 8, 8, seed=2)).to(dev)
+    img2 = torch.from_numpy(synth.synth_images(2, 64, 64, seed=5)).to(dev)
+    ann2 = torch.from_numpy(synth.synth_annotations(2, 64, 64, 4, 8, 8, seed=6)).to(dev)
+
+    def grads_of(i, a):
+        model.zero_grad()
+        cl, rl = model(i, a)
+        (cl + rl).sum().backward()
+        return [p.grad.clone() for p in model.parameters()]
+    ref1, ref2 = grads_of(img, ann), grads_of(img2, ann2)
+    # a validation-style call between the forward and the backward
+    model.zero_grad()
     cl, rl = model(img, ann)
-    model(img, return_head=True)
+    model(img2, return_head=True)
+    (cl + rl).sum().backward()
+    assert all(torch.equal(p.grad, r) for p, r in zip(model.parameters(), ref1))
+    # two micro-batches forwarded, then both backwards (gradient accumulation): each backward restores its own batch
+    model.zero_grad()
+    c1, r1 = model(img, ann)
+    c2, r2 = model(img2, ann2)
+    (c1 + r1).sum().backward()
+    g1 = [p.grad.clone() for p in model.parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(g1, ref1))
+    (c2 + r2).sum().backward()
+    for p, a, b in zip(model.parameters(), ref1, ref2):
+        assert torch.allclose(p.grad, a + b, rtol=1e-6, atol=1e-8)
+    # another SHAPE has its own plan: nothing to restore
+    other = torch.from_numpy(synth.synth_images(2, 96, 64, seed=3)).to(dev)
+    model.zero_grad()
+    cl, rl = model(img, ann)
+    model(other, return_head=True)
+    (cl + rl).sum().backward()
+    assert all(torch.equal(p.grad, r) for p, r in zip(model.parameters(), ref1))
+    # a parameter modified in place between the forward and the backward: raises (so does the reference's autograd)
+    model.zero_grad()
+    cl, rl = model(img, ann)
+    model(img2, return_head=True)
+    with torch.no_grad():
+        model.conv1.weight.mul_(1.0)
     with pytest.raises(RuntimeError, match='another forward'):
         (cl + rl).sum().backward()
-    cl, rl = model(img, ann)                                  # a fresh forward/backward pair still works
-    (cl + rl).sum().backward()
-    other = torch.from_numpy(synth.synth_images(2, 96, 64, seed=3)).to(dev)
+    # train-mode BatchNorm: the forward cannot be re-run silently
+    model.train()
     cl, rl = model(img, ann)
-    model(other, return_head=True)                            # another SHAPE has its own plan: fine
-    (cl + rl).sum().backward()
+    model(img2, ann2)
+    with pytest.raises(RuntimeError, match='train-mode BatchNorm'):
+        (cl + rl).sum().backward()
 
 
 def test_reduce_lr_on_plateau_drives_the_flat_optimizer():
