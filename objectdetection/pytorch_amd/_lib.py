@@ -40,6 +40,11 @@ def lib():
                         'mi355det: %s not built. Run `python -c "import __graft_entry__ as g; '
                         'g.build()"` or `make -C objectdetection/pytorch_amd/csrc`. '
                         'There is no CPU fallback.' % LIB_PATH)
+                # torch first: it bundles its own libamdhip64.so, and the library resolves its HIP calls against whichever
+                # runtime the process loaded FIRST.  Loaded before torch (build() then smoke() in one process), it bound
+                # the system runtime of /opt/rocm beside torch's: two HIP runtimes in one process, and the launches of this
+                # library failed with "no ROCm-capable device is detected" on a box where torch saw the GPU.
+                import torch  # noqa: F401
                 handle = ctypes.CDLL(LIB_PATH)
                 handle.mi355_last_error.restype = ctypes.c_char_p
                 _lib = handle

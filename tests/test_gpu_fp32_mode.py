@@ -66,7 +66,7 @@ def _check_grads(g, grads, dev):
     return worst
 
 
-@pytest.mark.parametrize('tag', ['r18_256', 'r50_128x160'])
+@pytest.mark.parametrize('tag', ['r18_256', 'r50_128x160', 'r34_64x96', 'r101_64x96'])
 def test_fp32_mode_vs_reference_golden(golden_dir, dev, tag):
     from objectdetection.pytorch_amd.architectures import retinanet
     g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))

@@ -19,7 +19,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.mi355_version() >= 1
 
 
-@pytest.mark.parametrize('tag,depth', [('r18_256', 18), ('r50_128x160', 50)])
+@pytest.mark.parametrize('tag,depth', [('r18_256', 18), ('r50_128x160', 50), ('r34_64x96', 34), ('r101_64x96', 101)])
 def test_state_dict_matches_reference(golden_dir, tag, depth):
     from objectdetection.pytorch_amd.architectures import retinanet
     g = np.load(os.path.join(golden_dir, 'e2e_%s.npz' % tag))
@@ -110,6 +110,28 @@ def test_efficientdet_state_dict_matches_reference(golden_dir, tag, coef):
         model(torch.zeros(1, 3, 128, 128), torch.zeros(1, 1, 5))          # no CPU fallback
     with pytest.raises(RuntimeError):
         efficientdet.EfficientDet(num_classes=3, compound_coef=0, load_weights=True)   # never fetch
+
+
+@pytest.mark.parametrize('coef', range(8))
+def test_every_efficientdet_variant_matches_the_reference_tables(golden_dir, coef):
+    """efficientdet.py:442-495 (compound-coefficient tables) and :588: D0 .. D7 built by the mirrored constructor have the
+    reference's state_dict keys and shapes, parameter count, anchor configuration and attention / plain-sum BiFPN choice
+    (fixture made by building every variant with the reference: tools/make_golden.py:gen_effdet_variants)."""
+    from objectdetection.pytorch_amd.architectures import efficientdet
+    g = np.load(os.path.join(golden_dir, 'effdet_variants.npz'))
+    model = efficientdet.build_efficientdet('efficientdet-d%d' % coef, num_classes=7)
+    sd = model.state_dict()
+    pre = 'd%d/' % coef
+    assert list(sd.keys()) == [str(k) for k in g[pre + 'keys']]
+    assert [','.join(map(str, v.shape)) for v in sd.values()] == [str(x) for x in g[pre + 'shapes']]
+    assert sum(p.numel() for p in model.parameters()) == int(g[pre + 'nparams'])
+    a = model.anchors
+    assert list(a.pyramid_levels) == list(g[pre + 'anchor_levels'])
+    np.testing.assert_allclose(np.array(a.strides, dtype=np.float64), g[pre + 'anchor_strides'])
+    np.testing.assert_allclose(np.array(a.sizes, dtype=np.float64), g[pre + 'anchor_sizes'])
+    np.testing.assert_allclose(np.array(a.ratios, dtype=np.float64), g[pre + 'anchor_ratios'])
+    np.testing.assert_allclose(np.array(a.scales, dtype=np.float64), g[pre + 'anchor_scales'])
+    assert [bool(getattr(c, 'attention', True)) for c in model.bifpn] == [bool(x) for x in g[pre + 'attention']]
 
 
 def test_wgrad_split_rows_are_whole_granules():

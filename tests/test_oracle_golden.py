@@ -78,7 +78,7 @@ def test_decode_clip(golden_dir):
     np.testing.assert_array_equal(ref_cpu.clip_boxes(boxes, int(h), int(w)).numpy(), g['clipped'])
 
 
-@pytest.mark.parametrize('tag', ['r18_256', 'r50_128x160'])
+@pytest.mark.parametrize('tag', ['r18_256', 'r50_128x160', 'r34_64x96', 'r101_64x96'])
 def test_retinanet_end_to_end(golden_dir, tag):
     g = _load(golden_dir, 'e2e_%s.npz' % tag)
     depth, (H, W), B, nc = int(g['depth']), g['hw'], int(g['batch']), int(g['num_classes'])

@@ -745,6 +745,30 @@ def gen_effdet_trainbn(coef, H, W, B, num_classes, tag, gain, head_std):
     print('e2e', tag, 'cls', cl.item(), 'reg', rl.item(), 'gnorm', d['grad_global_norm'])
 
 
+def gen_effdet_variants():
+    """State-dict keys / shapes, parameter counts and anchor configuration of every EfficientDet-D0 .. D7 the reference
+    builds (efficientdet.py:442-495 tables, :588 build_efficientdet): the host-API test checks the mirrored builders
+    against them (only D0 / D2 / D6 have end-to-end goldens)."""
+    from architectures import efficientdet as ref_eff
+    d = {}
+    for coef in range(8):
+        torch.manual_seed(0)
+        m = ref_eff.build_efficientdet('efficientdet-d%d' % coef, num_classes=7)
+        sd = m.state_dict()
+        d['d%d/keys' % coef] = np.array(list(sd.keys()))
+        d['d%d/shapes' % coef] = np.array([','.join(map(str, v.shape)) for v in sd.values()])
+        d['d%d/nparams' % coef] = np.array(sum(p.numel() for p in m.parameters()))
+        a = m.anchors
+        d['d%d/anchor_levels' % coef] = np.array(a.pyramid_levels)
+        d['d%d/anchor_strides' % coef] = np.array(a.strides, dtype=np.float64)
+        d['d%d/anchor_sizes' % coef] = np.array(a.sizes, dtype=np.float64)
+        d['d%d/anchor_ratios' % coef] = np.array(a.ratios, dtype=np.float64)
+        d['d%d/anchor_scales' % coef] = np.array(a.scales, dtype=np.float64)
+        d['d%d/attention' % coef] = np.array([bool(getattr(c, 'attention', True)) for c in m.bifpn])
+        print('effdet variant d%d: %d entries, %.2f M parameters, %d BiFPN cells' % (coef, len(sd), float(d['d%d/nparams' % coef]) / 1e6, len(m.bifpn)))
+    np.savez_compressed(os.path.join(OUT, 'effdet_variants.npz'), **d)
+
+
 def gen_effdet_drop_connect(coef, H, W, B, num_classes, tag, gain, head_std):
     """EfficientDet in the state the reference trains it in (train.py:273-286: `.train()` then `freeze_bn()`): the
     MBConv blocks are in train mode, so drop-connect (utils_efficientnet.py:85-94) draws one torch.rand per image
@@ -825,11 +849,16 @@ if __name__ == '__main__':
     if 'e2e' in which:
         gen_e2e(18, 256, 256, 2, 80, 'r18_256', 0.87)     # BASELINE.json configs[0]
         gen_e2e(50, 128, 160, 1, 20, 'r50_128x160', 0.78) # bottleneck path, ragged H != W
+    if 'e2e_depths' in which:                             # the other ResNet depths of retinanet.py:399-445 (basic / bottleneck)
+        gen_e2e(34, 64, 96, 1, 12, 'r34_64x96', 0.8)      # BasicBlock [3, 4, 6, 3]
+        gen_e2e(101, 64, 96, 1, 12, 'r101_64x96', 0.7)    # Bottleneck [3, 4, 23, 3]
     if 'effdet' in which:
         gen_e2e_effdet(0, 128, 128, 2, 8, 'effdet_d0_128', 1.0, 0.05)      # configs[3] family
         gen_e2e_effdet(2, 128, 256, 1, 5, 'effdet_d2_128x256', 1.0, 0.05)  # configs[4] family
     if 'effdet_trainbn' in which:
         gen_effdet_trainbn(0, 128, 256, 3, 8, 'effdet_d0_trainbn_128x256', 1.0, 0.05)
+    if 'effdet_variants' in which:
+        gen_effdet_variants()
     if 'effdet_dc' in which:
         gen_effdet_drop_connect(0, 128, 128, 4, 8, 'effdet_d0_dropconnect_128', 1.0, 0.05)
     if 'effdet6' in which:
