@@ -680,6 +680,7 @@ class RetinaPlan(object):
         split = pick_split_rows(rows, tiles, target_blocks=ops_conv.wgrad_target_blocks(spec.Kpad, spec.Cpad, spec.T, problems),
                                 min_rows=int(os.environ.get('MI355_WG_MINROWS', '1024')),
                                 granule=int(os.environ.get('MI355_WG_GRANULE', '64')))
+        split = self._fit_ring_split(problems, spec, tiles, split)
         self.keep.append(L)
         spec._wgrad_launch = L
         spec._wgrad_end = len(self.bwd_steps) + 1          # launches of the backward list needed for this dW
@@ -694,6 +695,19 @@ class RetinaPlan(object):
             spec.colsum = self.new((nslabs, spec.Kpad), torch.float32, zero=True)
         self._step(self.bwd_steps, 'mi355_conv_wgrad_slabs', ctypes.byref(L), ptr(spec.G), c_i64(slab),
                    c_int(nslabs), ptr(spec.colsum if colsum else None), c_int(split))
+
+    def _fit_ring_split(self, problems, spec, tiles, split):
+        """MI355_WG_X_FIT=1: launches of the eight-wave ring kernel (one block per CU) cut so that every block runs in ONE
+        round (ops_conv.fit_split_rows).  Measured and OFF: the head towers went 140 -> 148 us and the cls output 386 -> 573
+        us alone, the step lost 2 % - the launch ends with its LONGEST chunk (which the fit lengthens from 65 to 74
+        stages), and the 20 blocks past 256 are the shortest chunks of the longest-first order, which the CUs of the
+        short first-round chunks pick up for free."""
+        if (len(problems) > 1 and spec.T == 9 and os.environ.get('MI355_WG_X_FIT', '0') == '1' and
+                ops_conv.wgrad_row3x_ok(problems, spec.Cpad, spec.Kpad)):
+            cap = int(os.environ.get('MI355_WG_X_BLOCKS', '256'))
+            return ops_conv.fit_split_rows([p.N * p.P * p.Q for p in problems], tiles, cap, split,
+                                           int(os.environ.get('MI355_WG_GRANULE', '64')))
+        return split
 
     # -- same-shape weight gradients of a stage as ONE launch ---------------------------------------------------------
     # The identical bottleneck / basic blocks of a ResNet stage produce weight gradients of the same shape that are
@@ -729,6 +743,7 @@ class RetinaPlan(object):
                                 target_blocks=ops_conv.wgrad_target_blocks(spec0.Kpad, spec0.Cpad, spec0.T, problems),
                                 min_rows=int(os.environ.get('MI355_WG_MINROWS', '1024')),
                                 granule=int(os.environ.get('MI355_WG_GRANULE', '64')))
+        split = self._fit_ring_split(problems, spec0, tiles, split)
         n = len(group)
         ws, cs, cap = (c_vp * n)(), (c_vp * n)(), (c_int * n)()
         for j, (pr, spec, rows) in enumerate(group):

@@ -198,6 +198,19 @@ def wgrad_tiles(kpad, cpad, taps, problems=None):
     return kt * (-(-taps * cpad // 128)) if cpad < 128 else kt * taps * (-(-cpad // 128))
 
 
+def fit_split_rows(problem_rows, tiles_per_chunk, max_blocks, rows, granule=64):
+    """The smallest split >= `rows` (a multiple of `granule`) with sum_i ceil(M_i / split) * tiles <= max_blocks.
+    A grouped launch cuts every problem on its own, so the chunk count is sum_i ceil(M_i / split), not
+    ceil(sum_i M_i / split): the five pyramid levels of a head tower at 512^2 gave 23 chunks x 12 tiles = 276 blocks for
+    a target of 256 - with ONE eight-wave block per CU (the ring weight-gradient kernel) the last 20 blocks ran as a
+    second round behind the 65-stage chunks of the first."""
+    rows = max(granule, -(-rows // granule) * granule)
+    top = max(problem_rows)
+    while rows < top and sum(-(-m // rows) for m in problem_rows) * tiles_per_chunk > max_blocks:
+        rows += granule
+    return rows
+
+
 def pick_split_rows(total_rows, tiles_per_chunk, target_blocks=512, min_rows=512, granule=64):
     """Rows of the pixel reduction per block: ~2 four-wave blocks per CU, but never so few rows that
     the partial-tile epilogue (64 KiB per block) outweighs the MFMA work.  (Measured on R50 512^2

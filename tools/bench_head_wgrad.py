@@ -25,6 +25,8 @@ probs = [ops_conv.fwd_problem(x, dy.data_ptr(), 3, 3, 1, 1, K=K) for x, dy in zi
 rows = sum(B * s * s for s in sizes)
 tiles = ops_conv.wgrad_tiles(K, C, 9, probs)
 split = ops_conv.pick_split_rows(rows, tiles, target_blocks=ops_conv.wgrad_target_blocks(K, C, 9, probs), min_rows=1024, granule=64)
+if os.environ.get('MI355_WG_X_FIT', '0') == '1' and ops_conv.wgrad_row3x_ok(probs, C, K):          # as engine._fit_ring_split
+    split = ops_conv.fit_split_rows([B * s * s for s in sizes], tiles, int(os.environ.get('MI355_WG_X_BLOCKS', '256')), split)
 nslabs = sum(-(-(B * s * s) // split) for s in sizes)
 L = ops_conv.ConvLaunch()
 for j, pr in enumerate(probs):
