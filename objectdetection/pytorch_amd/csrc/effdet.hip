@@ -210,7 +210,7 @@ struct DwTileLevel {
 };
 struct DwTileLaunch {
     DwTileLevel lv[MI355_DW_MAX_LEVELS];
-    int nlevels, C, nc8, pad_t, pad_l, accumulate;
+    int nlevels, C, nc8, pad_t, pad_l, accumulate, xs;
     // NODE form (one level): the conv's input is the BiFPN fast-attention node z = w[0] in + w[1] in1' + w[2] in2
     // (efficientdet.py:213-265), built while the halo tile is staged and stored to `zout` by the tile that owns the
     // pixel (the backward reads z); in1' = nearest-2x upsample of in1 [N][H/2][W/2][C] when up1
@@ -251,19 +251,30 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, c
     float* wl = reinterpret_cast<float*>(smem + (size_t)nc8 * NPX * 16);     // [K*K][nc8*8]
     s8v* ot = reinterpret_cast<s8v*>(smem);                                // [nc8][DT_OS] output staging, aliases `tile`
     const int tid = threadIdx.x;
+    // Block order (as in dw_wgrad_tile_kernel): the channel groups of a tile read pieces of the same 128-B lines; in
+    // launch order (tiles fastest, then image x group) they run far apart and on different XCDs.  L.xs: XCD x takes a
+    // contiguous range of logical ids with the GROUP fastest, so the groups of a tile share one L2 while the lines are
+    // resident (a bijection of block ids: results unchanged).
+    const int groups = (L.C >> 3) / L.nc8;
+    int tile_id = blockIdx.x, img_group = blockIdx.y;
+    if (L.xs) {
+        const int lg = xcd_swizzle((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+        const int g = lg % groups, rest = lg / groups;
+        tile_id = rest % (int)gridDim.x;
+        img_group = (rest / (int)gridDim.x) * groups + g;
+    }
     DwTileLevel P = L.lv[0];
 #pragma unroll
     for (int i = 1; i < MI355_DW_MAX_LEVELS; ++i)
-        if (i < L.nlevels && (int)blockIdx.x >= L.lv[i].tile_begin) P = L.lv[i];
-    const int tl = blockIdx.x - P.tile_begin;
+        if (i < L.nlevels && tile_id >= L.lv[i].tile_begin) P = L.lv[i];
+    const int tl = tile_id - P.tile_begin;
     const int tyi = tl / P.tilesX, txi = tl - tyi * P.tilesX;
     const int q0 = txi * DT_TW, p0 = tyi * DT_TH;
     const int H = P.H, W = P.W, OP = P.P, OQ = P.Q;
     const unsigned short* __restrict__ in = P.in;
     unsigned short* __restrict__ out = P.out;
     const unsigned short* __restrict__ zin = P.zin;
-    const int groups = (C >> 3) / nc8;
-    const int n = blockIdx.y / groups, c8b = (blockIdx.y - n * groups) * nc8;
+    const int n = img_group / groups, c8b = (img_group - n * groups) * nc8;
     // ---- input halo tile
     for (int i = tid; i < IH * IW * nc8; i += 256) {
         const int lin = i / nc8, ch = i - lin * nc8;
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(256) void dw_tile_s1_kernel(const DwTileLaunch L, c
             const int ch = tid >> 3, e = tid & 7;
             const float t = (red[(0 * nc8 + ch) * 8 + e] + red[(1 * nc8 + ch) * 8 + e]) +
                             (red[(2 * nc8 + ch) * 8 + e] + red[(3 * nc8 + ch) * 8 + e]);
-            L.pool[((long long)n * gridDim.x + blockIdx.x) * C + (c8b + ch) * 8 + e] = t * L.pool_scale;
+            L.pool[((long long)n * gridDim.x + tile_id) * C + (c8b + ch) * 8 + e] = t * L.pool_scale;
         }
     }
 }
@@ -427,6 +438,8 @@ static int launch_dw_tile(const Mi355DwLevel* levels, int nlevels, const float* 
         L.zout = (unsigned short*)node->zout;  L.nodew = node->w;  L.up1 = node->up1;
     }
     L.nlevels = nlevels; L.C = C; L.pad_t = pad_t; L.pad_l = pad_l; L.accumulate = accumulate;
+    static const int dw_xcd = [] { const char* e = getenv("MI355_DW_XCD"); return e ? atoi(e) : 1; }();
+    L.xs = dw_xcd;
     L.nc8 = (S == 1 && c8n % 4 == 0) ? 4 : (c8n % 2 == 0 ? 2 : 1);        // stride 2: the halo tile is 4x the pixels
     long long tiles = 0;
     for (int i = 0; i < nlevels; ++i) {
@@ -1036,7 +1049,7 @@ struct DwWgLevel {
 };
 struct DwWgLaunch {
     DwWgLevel lv[MI355_DW_MAX_LEVELS];
-    int nlevels, ntiles, C, nc8, want_cs;
+    int nlevels, ntiles, C, nc8, want_cs, xs;
 };
 typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot2bf(unsigned a, unsigned b, float c) {
@@ -1060,7 +1073,17 @@ __global__ __launch_bounds__(32 * K * (K == 3 ? 4 : 2), (S == 2 ? 3 : (K == 3 ? 
     const int pl = tid & 31, slot = tid >> 5;               // slot = a * nc8 + ch
     const int a = slot / nc8, ch = slot - a * nc8;
     const int prow = pl / TW, pcol = pl - prow * TW;
-    const int c8b = blockIdx.x * nc8;
+    // Block order: the channel groups of a slab (= the same pixel tiles) read 16 .. 64-B pieces of the SAME 128-B lines,
+    // and consecutive block ids go round-robin over the 8 XCDs (one L2 each): in plain order every XCD fetched every
+    // line (PMC: 780 MB read by the 128^2 x 144 k5 / s2 launch for 94 MB of operands).  XCD x takes a contiguous range
+    // of logical ids instead, i.e. all channel groups of a slab (a bijection: results unchanged; L.xs == 0: plain order).
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (L.xs) {
+        const int lg = xcd_swizzle((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+        by = lg / (int)gridDim.x;
+        bx = lg - by * (int)gridDim.x;
+    }
+    const int c8b = bx * nc8;
     const int sc = tid % nc8, spx = tid / nc8;              // staging: this thread's chunk and first cell, stride 32 K
     float acc[K][8], cs[8];
 #pragma unroll
@@ -1070,7 +1093,7 @@ __global__ __launch_bounds__(32 * K * (K == 3 ? 4 : 2), (S == 2 ? 3 : (K == 3 ? 
         for (int b = 0; b < K; ++b) acc[b][e] = 0.0f;
     }
     const u4v zero = (u4v){0u, 0u, 0u, 0u};
-    for (int t = blockIdx.y; t < L.ntiles; t += gridDim.y) {
+    for (int t = by; t < L.ntiles; t += gridDim.y) {
         DwWgLevel P = L.lv[0];
 #pragma unroll
         for (int i = 1; i < MI355_DW_MAX_LEVELS; ++i)
@@ -1164,7 +1187,7 @@ __global__ __launch_bounds__(32 * K * (K == 3 ? 4 : 2), (S == 2 ? 3 : (K == 3 ? 
             for (int o = 16; o > 0; o >>= 1) acc[b][e] += __shfl_xor(acc[b][e], o, 64);
     }
     if (pl == 0 && a < K) {
-        float* row = slabs + (long long)blockIdx.y * (K * K + 1) * C + (c8b + ch) * 8;
+        float* row = slabs + (long long)by * (K * K + 1) * C + (c8b + ch) * 8;
 #pragma unroll
         for (int b = 0; b < K; ++b) {
             float* dst = row + (a * K + b) * C;
@@ -1255,6 +1278,8 @@ extern "C" int mi355_dwconv_wgrad_slabs_multi(const Mi355DwLevel* levels, int nl
                   "dwconv_wgrad_slabs: k must be 3 or 5, stride 1 or 2, C %% 8 == 0, 1..%d levels", MI355_DW_MAX_LEVELS);
     for (int i = 0; i < nlevels; ++i) MI355_REQUIRE(levels[i].x && levels[i].dy, "dwconv_wgrad_slabs: level %d null x / dy", i);
     L.want_cs = want_colsum;
+    static const int dw_xcd = [] { const char* e = getenv("MI355_DW_XCD"); return e ? atoi(e) : 1; }();
+    L.xs = dw_xcd;
 #define MI355_DWT2(KK, SS, SW)                                                                         \
     do {                                                                                               \
         if (tw == 32) launch_dw_wgrad_tile<KK, SS, SW, 32>(L, slabs, nslabs, stream);                  \
