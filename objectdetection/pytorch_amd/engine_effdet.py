@@ -745,8 +745,18 @@ class EffDetPlan(RetinaPlan):
 
     # ------------------------------------------------------------------ backward
     def _build_backward(self):
+        # Same-shape weight gradients of the pointwise convs are independent leaves of the backward pass: the 24 BiFPN node
+        # convs (64 -> 64 over 64^2 .. 4^2 maps: 9 us launches that fill a fraction of the chip), the expand / project convs
+        # of repeated MBConv blocks.  MI355_EFF_WG_GROUP=1: conv_bwd defers them and five of a kind (or the end of the
+        # tape) go out as ONE mi355_conv_wgrad_multi launch (engine.RetinaPlan._defer_wgrad); the gradient buffers a
+        # deferred launch reads are complete when its tape entry runs and nothing overwrites them.  Measured and OFF:
+        # 494 -> 459 launches per D0 step but 2 300 -> 2 235 img/s (D2 664 -> 650): the side stream, which already
+        # finishes behind main, gets its work later, and the grouped launch of five tiny maps is no faster than five.
+        self._grouping_wgrads = self._wgrad_grouping_ok() and os.environ.get('MI355_EFF_WG_GROUP', '0') == '1'
         for fn in reversed(self.tape):
             fn()
+        self._grouping_wgrads = False
+        self._flush_wgrads()
         self._build_param_grads()
 
     def _step(self, lst, name, *args):
