@@ -192,8 +192,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const void* __restrict__ 
     const int c0 = (int)((i * 8) % C);
     float v[8];
     load8<F32>(z, i * 8, v);
+    // per-channel coefficients as two 16-B loads per row (C % 8 == 0, 16-B aligned state) instead of eight scalar ones
+    float sc[8], sh[8];
+    load8<true>(state, (long long)ST_SCALE * C + c0, sc);
+    load8<true>(state, (long long)ST_SHIFT * C + c0, sh);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * state[ST_SCALE * C + c0 + e] + state[ST_SHIFT * C + c0 + e];
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
     if (addend) {
         float ad[8];
         load8<F32>(addend, i * 8, ad);
@@ -219,12 +223,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const void* __restric
     float vg[8], vz[8];
     load8<F32>(g, i * 8, vg);
     load8<F32>(z, i * 8, vz);
+    float mean[8], is[8], sc[8], th[8], s0[8], s1[8];      // 16-B coefficient loads (see bn_apply_kernel)
+    load8<true>(state, (long long)ST_MEAN * C + c0, mean);
+    load8<true>(state, (long long)ST_INVSTD * C + c0, is);
+    load8<true>(state, (long long)ST_SCALE * C + c0, sc);
+    load8<true>(state, (long long)ST_THROUGH * C + c0, th);
+    load8<true>(sums, (long long)c0, s0);
+    load8<true>(sums, (long long)C + c0, s1);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int c = c0 + e;
-        const float zhat = (vz[e] - state[ST_MEAN * C + c]) * state[ST_INVSTD * C + c];
-        const float mg = sums[c] * inv_count, mgz = sums[C + c] * inv_count * state[ST_THROUGH * C + c];
-        vg[e] = state[ST_SCALE * C + c] * (vg[e] - mg - zhat * mgz);
+        const float zhat = (vz[e] - mean[e]) * is[e];
+        const float mg = s0[e] * inv_count, mgz = s1[e] * inv_count * th[e];
+        vg[e] = sc[e] * (vg[e] - mg - zhat * mgz);
     }
     store8<F32>(dz, i * 8, vg);
 }
@@ -286,6 +296,7 @@ extern "C" int mi355_bn_nhwc_finalize(const float* sums, float count, int C, flo
 extern "C" int mi355_bn_nhwc_apply(const void* z, const float* state, const void* addend, int act, int f32, int64_t M,
                                    int C, void* y, void* stream) {
     MI355_REQUIRE(z && state && y && M > 0 && C > 0 && C % 8 == 0 && (act == 0 || act == 1), "bn_nhwc_apply: bad args");
+    MI355_REQUIRE(((uintptr_t)state & 15) == 0, "bn_nhwc_apply: the layer state must be 16-B aligned");
     const long long n8 = (long long)M * C / 8;
     const dim3 g((unsigned)cdiv(n8, 256)), b(256);
     if (f32) hipLaunchKernelGGL(bn_apply_kernel<true>, g, b, 0, (hipStream_t)stream, z, state, addend, act, n8, C, y);
@@ -296,6 +307,7 @@ extern "C" int mi355_bn_nhwc_apply(const void* z, const float* state, const void
 extern "C" int mi355_bn_nhwc_bwd_apply(const void* g, const void* z, const float* state, const float* sums,
                                        float inv_count, int f32, int64_t M, int C, void* dz, void* stream) {
     MI355_REQUIRE(g && z && state && sums && dz && M > 0 && C > 0 && C % 8 == 0, "bn_nhwc_bwd_apply: bad args");
+    MI355_REQUIRE(((uintptr_t)state & 15) == 0 && ((uintptr_t)sums & 15) == 0, "bn_nhwc_bwd_apply: state / sums must be 16-B aligned");
     const long long n8 = (long long)M * C / 8;
     const dim3 gr((unsigned)cdiv(n8, 256)), b(256);
     if (f32) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, gr, b, 0, (hipStream_t)stream, g, z, state, sums, inv_count, n8, C, dz);
