@@ -672,7 +672,20 @@ __device__ __forceinline__ void lds_write16(unsigned addr, i4v v) {
 __device__ __forceinline__ int x3_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
 // ABL: diagnostic builds (MI355_X3_ABLATE, tools/bench_head_wgrad.py; 0 = the kernel): 1 no LDS-DMA in the loop, 2 no fragment
-// reads in the loop, 4 no epilogue stores, 8 no MFMAs.  Results are garbage for ABL != 0.
+// reads in the loop, 4 no epilogue stores, 8 no MFMAs (sums: 3, 7, 9, 10, 11).  Results are garbage for ABL != 0.
+// Head towers alone, us: 0: 132 | 1: 118 | 2: 114 | 3: 97 | 4: 125 | 7: 90 | 8: 93 | 9: 71 | 10: 69 | 11: 45 - the parts ADD
+// (skeleton 45 incl. a second round of 20 short blocks, MFMAs +45 .. 52, reads +26, DMA +24).  What round 3 built on top of
+// this loop, measured and took out again:
+//  * the three column taps formed in registers from ONE set of transposed reads (14 reads per 24 MFMAs instead of 20,
+//    v_alignbit + edge masks, ~30 VALU ops per group): 131 -> 138 - 142 us.  The LDS array is not the limit (a transposed read
+//    is 2 LDS cycles), the vector issue slots beside the MFMAs are.
+//  * ping-pong roles (waves w and w + 4 of a SIMD alternate a bare 48-MFMA phase with a load phase, two barriers per stage):
+//    in-kernel cycle stamps show the compute phase AT its floor (800 cycles for 768 of MFMA) but a load phase of 1 370 - 1 460
+//    cycles (reads alone 790 = 20 per read; pixel-row reads + offsets + five DMA pieces alone 930: a piece costs its wave
+//    ~120 cycles with four waves issuing at once), so a stage takes 3 660 cycles against ~2 900 here: 134 -> 151 us.  s_setprio
+//    for the loading wave: no change.  The load work of a stage (2 x 1 400 wave-cycles per SIMD) does not fit beside its
+//    1 536 cycles of MFMA in either arrangement; less of it per MFMA needs a larger block tile than the register file holds.
+//  * waves 4-7 issuing their DMA pieces half a stage after their SIMD partners: 140 vs 141 us.  Column sums off: no change.
 template <int ABL>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1202,6 +1215,9 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
             (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
             x3_attr = true;
         }
         const char* ae = getenv("MI355_X3_ABLATE");               // diagnostic builds (not cached: a bench tool sweeps it)
@@ -1212,6 +1228,9 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
             case 4: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<4>, g, dim3(512), X3_LDS, st, L); break;
             case 7: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<7>, g, dim3(512), X3_LDS, st, L); break;
             case 8: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<8>, g, dim3(512), X3_LDS, st, L); break;
+            case 9: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<9>, g, dim3(512), X3_LDS, st, L); break;
+            case 10: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<10>, g, dim3(512), X3_LDS, st, L); break;
+            case 11: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<11>, g, dim3(512), X3_LDS, st, L); break;
             default: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<0>, g, dim3(512), X3_LDS, st, L);
         }
     } else if (row3) {

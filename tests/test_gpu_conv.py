@@ -367,11 +367,12 @@ def test_conv_wgrad_ring_form(dev, case, split):
     _close(outs[0][1][:K], dy.sum((0, 2, 3)), 1e-3)
 
 
-def test_conv_wgrad_ring_form_grouped_levels(dev):
-    """Five pyramid levels of a shared-weight head conv in ONE ring-form launch (chunks sorted by length)."""
+@pytest.mark.parametrize('sizes', [[(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)], [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)],
+                                   [(8, 32), (12, 4), (3, 64)]], ids=['to-1x1', 'to-4x4', 'ragged'])
+def test_conv_wgrad_ring_form_grouped_levels(dev, sizes):
+    """Pyramid levels of a shared-weight head conv in ONE ring-form launch (chunks sorted by length)."""
     from objectdetection.pytorch_amd import ops_conv
     N, C, K = 2, 256, 256
-    sizes = [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
     xs = [_mk((N, C, h, w), 30 + i) for i, (h, w) in enumerate(sizes)]
     dys = [_mk((N, K, h, w), 40 + i) for i, (h, w) in enumerate(sizes)]
     keep, probs = [], []

@@ -1,6 +1,7 @@
 """The head-tower weight gradient of RetinaNet-R50 512^2 bs16 (five pyramid levels, C = K = 256, 3x3: the largest single
 launch class of the step) timed alone, slab mode as the plans run it.  MI355_WG_ROW3X=0/1 selects the four-wave /
 eight-wave ring kernel, MI355_X3_ABLATE the diagnostic builds of the ring kernel (conv_wgrad.hip).
+NO_COLSUM=1: without the column sums (bias gradient).
 Usage: python tools/bench_head_wgrad.py [iters] [K]"""
 import ctypes
 import os
@@ -36,7 +37,7 @@ slab = K * 9 * C
 ws = torch.empty(nslabs, slab, device=dev)
 cs = torch.zeros(nslabs, K, device=dev)
 st = c_vp(torch.cuda.current_stream().cuda_stream)
-args = (ctypes.byref(L), ptr(ws), c_i64(slab), c_int(nslabs), ptr(cs), c_int(split), st)
+args = (ctypes.byref(L), ptr(ws), c_i64(slab), c_int(nslabs), None if os.environ.get('NO_COLSUM') else ptr(cs), c_int(split), st)
 for _ in range(3):
     _lib.call('mi355_conv_wgrad_slabs', *args)
 torch.cuda.synchronize()
