@@ -60,6 +60,7 @@ struct WLaunch {
     // pyramid levels fill the tail of the launch instead of opening a second round of full-length blocks
     int ub;                                     // XCD-local unit size in logical blocks (1: none)
     int xs;                                     // > 0: XCD-aware block order in waves of xs blocks (wg_logical_block)
+    int wide;                                   // slab mode, every dw / slab stride 16-B aligned: 16-B epilogue stores
     int nsorted;                                // 0: chunk -> problem by chunk_begin (single problem)
     unsigned char ch_prob[MAX_SORTED];
     int ch_mbegin[MAX_SORTED];
@@ -343,6 +344,29 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
         }
     }
     const long long wrow = (long long)L.T * P.C;
+    if (L.wide) {
+        // 16-B stores: lane & 31 owns four columns (C % 4 == 0: one tap, contiguous), the two halves of a wave two rows
+        const int c = 4 * (lane & 31);
+        long long co = -1;
+        if (FLAT) {
+            const int J8 = c_tile * TC + c;
+            const int tp = J8 / P.C, cc = J8 - tp * P.C;
+            const int ti = tp / P.TS, tj = tp - ti * P.TS;
+            if (tp < P.TR * P.TS) co = (long long)((P.r0 + ti * P.rs) * P.S + (P.s0 + tj * P.ss)) * P.C + cc;
+        } else {
+            const int ti = tap / P.TS, tj = tap - ti * P.TS;
+            if (c0 + c < P.C) co = (long long)((P.r0 + ti * P.rs) * P.S + (P.s0 + tj * P.ss)) * P.C + c0 + c;
+        }
+        if (co >= 0) {
+            for (int rr = 2 * wv + (lane >> 5); rr < TK; rr += 8 * NG) {
+                const int k = k0 + rr;
+                if (k >= L.K) continue;
+                *reinterpret_cast<float4*>(P.dw + k * wrow + co + (long long)lchunk_id * L.slab_stride) =
+                    *reinterpret_cast<const float4*>(epi + rr * EPI_LD + c);
+            }
+        }
+        return;
+    }
     long long coff[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                      // weight-row offset of this lane's columns
@@ -622,13 +646,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
                     epi[(wk * 64 + i * 16 + fq * 4 + r) * R3_EPI_LD + wc * (KH ? 16 : 32) + j * 16 + fr] = acc[s3][i][j][r];
         __syncthreads();
         const long long coff = (long long)((P.r0 + kr * P.rs) * P.S + (P.s0 + s3 * P.ss)) * P.C + c0 + lane;
-        for (int rr = wv; rr < TK; rr += 4) {
-            const int k = k0 + rr;
-            if (k >= L.K) break;
-            float* dst = P.dw + k * wrow + coff;
-            const float v = epi[rr * R3_EPI_LD + lane];
-            if (L.slab_stride > 0) dst[(long long)lchunk_id * L.slab_stride] = v;
-            else atomicAdd(dst, v);
+        if (L.wide) {                                   // 16-B stores: four 256-B row segments per instruction
+            const int l16 = lane & 15;
+            for (int rr = 4 * wv + (lane >> 4); rr < TK; rr += 16) {
+                const int k = k0 + rr;
+                if (k >= L.K) continue;
+                *reinterpret_cast<float4*>(P.dw + k * wrow + (coff - lane) + 4 * l16 + (long long)lchunk_id * L.slab_stride) =
+                    *reinterpret_cast<const float4*>(epi + rr * R3_EPI_LD + 4 * l16);
+            }
+        } else {
+            for (int rr = wv; rr < TK; rr += 4) {
+                const int k = k0 + rr;
+                if (k >= L.K) break;
+                float* dst = P.dw + k * wrow + coff;
+                const float v = epi[rr * R3_EPI_LD + lane];
+                if (L.slab_stride > 0) dst[(long long)lchunk_id * L.slab_stride] = v;
+                else atomicAdd(dst, v);
+            }
         }
         __syncthreads();
     }
@@ -974,16 +1008,29 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
                     epi[(wk * 64 + i * 16 + fq * 4 + r) * X3_EPI_LD + wc * 32 + j * 16 + fr] = acc[s3][i][j][r];
         __syncthreads();
         const long long coff = (long long)((P.r0 + kr * P.rs) * P.S + (P.s0 + s3 * P.ss)) * P.C + c0 + lane;
-        for (int rr = wv; rr < TK; rr += 8) {
-            const int k = k0 + rr;
-            if (k >= L.K) break;
-            float* dst = P.dw + k * wrow + coff;
+        if (L.wide) {
+            // 1 KiB per store instruction (two 512-B row segments): the tail of a block is store-ISSUE bound, and every
+            // block of the launch reaches it at about the same time
+            const int l32 = lane & 31;
+            for (int rr = 2 * wv + (lane >> 5); rr < TK; rr += 16) {
+                const int k = k0 + rr;
+                if (k >= L.K) continue;
+                const float4 v = *reinterpret_cast<const float4*>(epi + rr * X3_EPI_LD + 4 * l32);
+                if (ABL & 4) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); continue; }
+                *reinterpret_cast<float4*>(P.dw + k * wrow + (coff - lane) + 4 * l32 + (long long)lchunk_id * L.slab_stride) = v;
+            }
+        } else {
+            for (int rr = wv; rr < TK; rr += 8) {
+                const int k = k0 + rr;
+                if (k >= L.K) break;
+                float* dst = P.dw + k * wrow + coff;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float v = epi[rr * X3_EPI_LD + h * 64 + lane];
-                if (ABL & 4) { asm volatile("" :: "v"(v)); continue; }
-                if (L.slab_stride > 0) dst[(long long)lchunk_id * L.slab_stride + h * 64] = v;
-                else atomicAdd(dst + h * 64, v);
+                for (int h = 0; h < 2; ++h) {
+                    const float v = epi[rr * X3_EPI_LD + h * 64 + lane];
+                    if (ABL & 4) { asm volatile("" :: "v"(v)); continue; }
+                    if (L.slab_stride > 0) dst[(long long)lchunk_id * L.slab_stride + h * 64] = v;
+                    else atomicAdd(dst + h * 64, v);
+                }
             }
         }
         __syncthreads();
@@ -1193,6 +1240,12 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
         return e ? atoi(e) : 1;
     }();
     L.xs = !xcd_mode ? 0 : (row3x ? 256 : 512);            // blocks resident at once: one / two per CU
+    static const int wide_mode = [] {                       // MI355_WG_WIDE=0: 4-B epilogue stores (A/B)
+        const char* e = getenv("MI355_WG_WIDE");
+        return e ? atoi(e) : 1;
+    }();
+    L.wide = wide_mode && slab_stride > 0 && slab_stride % 4 == 0 && C % 4 == 0;
+    for (int i = 0; i < in.nprob && L.wide; ++i) L.wide = ((uintptr_t)L.p[i].dw & 15) == 0;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
