@@ -579,20 +579,28 @@ extern "C" int mi355_prep_weights_table(const Mi355LayerDesc* d_table, int nlaye
 }
 
 // sum of slabs [lo, hi) of one 16-B piece of a layer's raw weight gradient, in index order
+// (slabs are written once by the weight-gradient launches and read once, here: non-temporal loads leave L2 / the Infinity
+// Cache to the activations the rest of the backward pass still reads: +0.2 % on the R50 step, A/B of two builds)
+typedef float pg_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 pg_load(const float4* p) {
+    const pg_f4 v = __builtin_nontemporal_load(reinterpret_cast<const pg_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float4 pg_sum_slabs(const Mi355LayerDesc& d, long long off, int lo, int hi) {
     const float4* gp = reinterpret_cast<const float4*>(d.G + off);
     const long long ss4 = d.slab_stride >> 2;
     float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int sl = lo;
     for (; sl + 4 <= hi; sl += 4) {                      // four slab loads in flight, added in index order
-        const float4 v0 = gp[sl * ss4], v1 = gp[(sl + 1) * ss4], v2 = gp[(sl + 2) * ss4], v3 = gp[(sl + 3) * ss4];
+        const float4 v0 = pg_load(gp + sl * ss4), v1 = pg_load(gp + (sl + 1) * ss4), v2 = pg_load(gp + (sl + 2) * ss4),
+                     v3 = pg_load(gp + (sl + 3) * ss4);
         g4.x += v0.x; g4.y += v0.y; g4.z += v0.z; g4.w += v0.w;
         g4.x += v1.x; g4.y += v1.y; g4.z += v1.z; g4.w += v1.w;
         g4.x += v2.x; g4.y += v2.y; g4.z += v2.z; g4.w += v2.w;
         g4.x += v3.x; g4.y += v3.y; g4.z += v3.z; g4.w += v3.w;
     }
     for (; sl < hi; ++sl) {
-        const float4 v = gp[sl * ss4];
+        const float4 v = pg_load(gp + sl * ss4);
         g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
     }
     return g4;

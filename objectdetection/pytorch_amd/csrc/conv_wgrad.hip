@@ -82,6 +82,13 @@ __device__ __forceinline__ void lds_wait() {
     __builtin_amdgcn_sched_barrier(0);      // keep the MFMAs behind the wait (guide §5.4 rule 18)
 }
 
+// Slab store of four columns; nt: the slab is written once and read once by the parameter-gradient table kernel, after the
+// launch - kept out of the way of the operand rows that the other blocks of the chunk still want from L2.
+__device__ __forceinline__ void slab_store4(float* dst, const float4 v, const bool nt) {
+    if (nt) __builtin_nontemporal_store((f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(dst));
+    else    *reinterpret_cast<float4*>(dst) = v;
+}
+
 // XCD-aware block order.  Consecutive blockIdx go round-robin over the 8 XCDs (one L2 each), and the (tap / kernel
 // row, k tile, c tile) blocks of a pixel chunk - consecutive LOGICAL ids - read the same dy / activation rows: in plain
 // order every chunk's rows are fetched into all eight L2s (PMC: 391 MB read per head-tower launch for 90 MB of operands).
@@ -361,8 +368,8 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_kernel(const WLaunch L
             for (int rr = 2 * wv + (lane >> 5); rr < TK; rr += 8 * NG) {
                 const int k = k0 + rr;
                 if (k >= L.K) continue;
-                *reinterpret_cast<float4*>(P.dw + k * wrow + co + (long long)lchunk_id * L.slab_stride) =
-                    *reinterpret_cast<const float4*>(epi + rr * EPI_LD + c);
+                slab_store4(P.dw + k * wrow + co + (long long)lchunk_id * L.slab_stride,
+                            *reinterpret_cast<const float4*>(epi + rr * EPI_LD + c), L.wide == 2);
             }
         }
         return;
@@ -651,8 +658,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
             for (int rr = 4 * wv + (lane >> 4); rr < TK; rr += 16) {
                 const int k = k0 + rr;
                 if (k >= L.K) continue;
-                *reinterpret_cast<float4*>(P.dw + k * wrow + (coff - lane) + 4 * l16 + (long long)lchunk_id * L.slab_stride) =
-                    *reinterpret_cast<const float4*>(epi + rr * R3_EPI_LD + 4 * l16);
+                slab_store4(P.dw + k * wrow + (coff - lane) + 4 * l16 + (long long)lchunk_id * L.slab_stride,
+                            *reinterpret_cast<const float4*>(epi + rr * R3_EPI_LD + 4 * l16), L.wide == 2);
             }
         } else {
             for (int rr = wv; rr < TK; rr += 4) {
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
                 if (k >= L.K) continue;
                 const float4 v = *reinterpret_cast<const float4*>(epi + rr * X3_EPI_LD + 4 * l32);
                 if (ABL & 4) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); continue; }
-                *reinterpret_cast<float4*>(P.dw + k * wrow + (coff - lane) + 4 * l32 + (long long)lchunk_id * L.slab_stride) = v;
+                slab_store4(P.dw + k * wrow + (coff - lane) + 4 * l32 + (long long)lchunk_id * L.slab_stride, v, L.wide == 2);
             }
         } else {
             for (int rr = wv; rr < TK; rr += 8) {
@@ -1246,6 +1253,11 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
     }();
     L.wide = wide_mode && slab_stride > 0 && slab_stride % 4 == 0 && C % 4 == 0;
     for (int i = 0; i < in.nprob && L.wide; ++i) L.wide = ((uintptr_t)L.p[i].dw & 15) == 0;
+    static const int nt_mode = [] {                         // MI355_WG_NT=0: plain slab stores (A/B: +0.7 % on the R50 step with nt)
+        const char* e = getenv("MI355_WG_NT");
+        return e ? atoi(e) : 1;
+    }();
+    if (L.wide && nt_mode) L.wide = 2;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(1));
