@@ -702,6 +702,7 @@ constexpr int X3_LDS = X3_TAB_OFF + X3_TABN * 16;
 static_assert(TK * X3_EPI_LD * 4 <= X3_TAB_OFF, "epilogue staging must fit in the ring");
 
 typedef int i4v __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ i4v lds_read16(unsigned addr) {
     i4v v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
@@ -727,7 +728,14 @@ __device__ __forceinline__ int x3_f(int row) { return (row & 3) | (((row >> 3) &
 //    for the loading wave: no change.  The load work of a stage (2 x 1 400 wave-cycles per SIMD) does not fit beside its
 //    1 536 cycles of MFMA in either arrangement; less of it per MFMA needs a larger block tile than the register file holds.
 //  * waves 4-7 issuing their DMA pieces half a stage after their SIMD partners: 140 vs 141 us.  Column sums off: no change.
-template <int ABL>
+// M32: the products as v_mfma_f32_32x32x16_bf16 (a wave's 64 k x 32 c x 3 taps = 3 x 2 tiles of 32 x 32).  Same operand
+// bytes and the same 20 transposed reads per 32 pixels, but 12 MFMAs instead of 24: an MFMA holds the SIMD's vector issue
+// port for 8 cycles whether it keeps the matrix pipe busy for 16 (16x16x32) or 32 cycles (32x32x16), and the port - shared
+// by the two waves of a SIMD - is what paces this loop (the ablation times add, see above).  LDS images: 16-B chunk c of
+// row r at slot c ^ ((r & 3) << 2): the two lane groups of a 32-lane half read the SAME four rows, 64 B each -> four
+// distinct 64-B bank quarters; rows that differ by a multiple of four share the swizzle, so the reads of a lane differ
+// by immediates (19 address registers instead of 28).
+template <int ABL, bool M32 = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch L) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -764,12 +772,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
     // staging: a DMA wave-instruction fills 4 rows of 256 B; piece pc = 8 i + wave (i = 0, 1) holds rows 4 pc .. 4 pc + 3,
     // lane -> (row 4 pc + lane / 16, slot lane % 16), source chunk slot ^ (f(row) << 1); f is the same for i = 0, 1.
     // Activation rows 64 .. 71 (pieces 16, 17): waves 0 and 1.
+    auto swz = [](const int row) { return M32 ? (row & 3) << 2 : x3_f(row) << 1; };     // XOR on the 16-B chunk index
     const int srow = 4 * wv + (lane >> 4), slot = lane & 15;
-    const int chunk8 = (slot ^ (x3_f(srow) << 1)) << 3;
+    const int chunk8 = (slot ^ swz(srow)) << 3;
     const int ky = k0 + chunk8, cx = c0 + chunk8;
     const bool ky_ok = ky + 8 <= L.K;
     const int xrow2 = 64 + 4 * wv + (lane >> 4);                      // (waves 0, 1)
-    const int cx2 = c0 + ((slot ^ (x3_f(xrow2) << 1)) << 3);
+    const int cx2 = c0 + ((slot ^ swz(xrow2)) << 3);
     const int xdelta = dh * P.W * P.C;
 
     // pixel-row ring, entry (e + 1) & 1023 <-> pixel m_begin + e, e >= -1:
@@ -841,12 +850,18 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
     };
 
     f4v acc[3][4][2];
+    f16v acc32[3][2];                                       // M32: [tap][32-k tile]
 #pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3)
+    for (int s3 = 0; s3 < 3; ++s3) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[s3][i][j] = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc32[s3][kt][v] = 0.f;
+    }
 
     const int wk = wv >> 2, wc = wv & 3;
     const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
@@ -879,6 +894,34 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
             }
         }
 
+    // M32 fragment addresses.  Lane group g: 16-column half kh = g & 1 of the 32-wide operand, pixel half hh = g >> 1 (8 pixels
+    // of the 16 of an MFMA); a transposed read covers rows 32 sub + 16 pg + 8 hh + 4 h + q4 (+ tap).  A: base per 32-k tile;
+    // B: one base for the middle tap, and for the edge taps one register per (sub, pg, h) - the zero row or base + offset.
+    const int hh = g >> 1, kh = g & 1, rowm = 8 * hh + q4;
+    unsigned adyM[2], adxM1 = 0, adxE[2][2][2][2];
+    if constexpr (M32) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+            adyM[kt] = rowm * 256 + (((8 * wk + 4 * kt + 2 * kh + (p4 >> 1)) ^ (q4 << 2)) << 4) + half8;
+        const int cb = 4 * wc + 2 * kh + (p4 >> 1);
+        adxM1 = X3_DY_BYTES + (rowm + 1) * 256 + ((cb ^ (((q4 + 1) & 3) << 2)) << 4) + half8;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int i = 32 * sub + 16 * pg + rowm + 4 * h;
+                        const int q = i & (P.W - 1), row = i + 2 * e;
+                        const bool edge = e == 0 ? q == 0 : q == P.W - 1;
+                        adxE[e][sub][pg][h] = lds0 + (edge ? ZROW + half8
+                                                           : X3_DY_BYTES + row * 256 + ((cb ^ ((row & 3) << 2)) << 4) + half8);
+                    }
+        adyM[0] += lds0;  adyM[1] += lds0;  adxM1 += lds0;    // (stage 0)
+    }
+
     const bool do_colsum = P.colsum != nullptr && c_tile == 0 && kr == 0 && wc == 0;
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
     const int nsteps = (m_end - m_begin + RM - 1) / RM;
@@ -889,7 +932,39 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
     // does not depend on its SIMD partner being in the opposite phase.  Raw 8-byte halves until the wait that
     // retires them; the s8v operands are formed after it.
     s4v fa0[2][4], fa1[2][4], fb0[2][3][2], fb1[2][3][2];
+    s4v ga[2][2][2][2], gb[2][2][3][2];                     // M32: [buf][pg][32-k tile | tap][h]
+    auto tr_off = [&](const unsigned a, const int off) {    // off = 8192 sub + 4096 pg + 1024 h: compile-time at every call
+        return off == 0 ? lds_tr<0>(a) : off == 1024 ? lds_tr<1024>(a) : off == 4096 ? lds_tr<4096>(a) : off == 5120 ? lds_tr<5120>(a)
+             : off == 8192 ? lds_tr<8192>(a) : off == 9216 ? lds_tr<9216>(a) : off == 12288 ? lds_tr<12288>(a) : lds_tr<13312>(a);
+    };
+    // M32: the 19 fragment addresses are kept ABSOLUTE (stage base included) and moved on once per stage (`m32_advance`):
+    // a read is one LDS instruction, no address add beside the MFMAs
+    auto m32_advance = [&](const int to_step) {              // from the buffer of stage to_step - 1 to that of to_step
+        const int d = (to_step % X3_NST) == 0 ? -(X3_NST - 1) * X3_STAGE : X3_STAGE;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) adyM[kt] += d;
+        adxM1 += d;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) adxE[e][sub][pg][h] += d;
+    };
     auto read_one = [&](const int buf, const int r, const unsigned sbn, const int subn) {   // r = 0 .. 19, all compile-time
+        if constexpr (M32) {
+            if (r < 8) {                                    // (sbn unused: the addresses carry their stage)
+                const int pg = r >> 2, kt = (r >> 1) & 1, h = r & 1;
+                ga[buf][pg][kt][h] = tr_off(adyM[kt], subn * 8192 + pg * 4096 + h * 1024);
+            } else {
+                const int rr = r - 8, pg = rr / 6, s3 = (rr % 6) >> 1, h = rr & 1;
+                if (s3 == 1) gb[buf][pg][s3][h] = tr_off(adxM1, subn * 8192 + pg * 4096 + h * 1024);
+                else         gb[buf][pg][s3][h] = lds_tr<0>(adxE[s3 >> 1][subn][pg][h]);
+            }
+            return;
+        }
         if (r < 8) {
             const int t = r >> 1;
             const unsigned a = sbn + ady[t] + subn * 8192;
@@ -904,6 +979,45 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
     };
     // the 24 MFMAs of group `buf`, with the reads of group (sbn, subn) into the other buffer between them (rd: issue them)
     auto group = [&](const int buf, auto rd, const unsigned sbn, const int subn, const bool dma) {   // rd: std::true_type / false_type; dma: wave-uniform
+        if constexpr (M32) {
+            s8v a2[2][2], b2[2][3];
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    a2[pg][kt] = (s8v){ga[buf][pg][kt][0][0], ga[buf][pg][kt][0][1], ga[buf][pg][kt][0][2], ga[buf][pg][kt][0][3],
+                                       ga[buf][pg][kt][1][0], ga[buf][pg][kt][1][1], ga[buf][pg][kt][1][2], ga[buf][pg][kt][1][3]};
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3)
+                    b2[pg][s3] = (s8v){gb[buf][pg][s3][0][0], gb[buf][pg][s3][0][1], gb[buf][pg][s3][0][2], gb[buf][pg][s3][0][3],
+                                       gb[buf][pg][s3][1][0], gb[buf][pg][s3][1][1], gb[buf][pg][s3][1][2], gb[buf][pg][s3][1][3]};
+            }
+            if (do_colsum) {
+#pragma unroll
+                for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) csum[kt] += bf16_to_f32((unsigned short)a2[pg][kt][e]);
+            }
+            // 12 MFMAs; the 20 reads of the next group two by two behind the first ten, the five DMA pieces behind 1, 3, .. 9
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {
+                const int pg = m / 6, s3 = (m % 6) >> 1, kt = m & 1;
+                if constexpr (!(ABL & 8)) acc32[s3][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[pg][kt], b2[pg][s3], acc32[s3][kt], 0, 0, 0);
+                else { asm volatile("" :: "v"(a2[pg][kt]), "v"(b2[pg][s3])); }
+                if (m < 10) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (decltype(rd)::value && !(ABL & 2)) {
+                        read_one(buf ^ 1, 2 * m, sbn, subn);
+                        read_one(buf ^ 1, 2 * m + 1, sbn, subn);
+                    }
+                    if ((m & 1) == 1 && dma) issue_piece(m >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            return;
+        }
         s8v af[4], bf[3][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -964,6 +1078,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
         lds_wait();                                                 // group (step, 0) is in buffer 0
         const bool dma = !(ABL & 1) && step + X3_NST < nsteps;
         group(0, std::true_type{}, sb, 1, false);                   // ... and (step, 1) on its way into buffer 1
+        if constexpr (M32) m32_advance(step + 1);                   // the next reads are those of (step + 1, 0)
         if (dma) issue_prep(step + X3_NST);                         // pixel rows of the stage to issue behind the barrier
         lds_wait();                                                 // this wave has read stage `step` out
         if (dma) issue_offsets();
@@ -987,7 +1102,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    if (do_colsum) {
+    if (do_colsum && M32) {                                 // lane & 31 = k inside the 32-k tile, lane >> 5 = pixel half
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            float v = csum[kt];
+            v += __shfl_xor(v, 32, 64);
+            const int k = k0 + wk * 64 + kt * 32 + (lane & 31);
+            if (lane < 32 && k < L.K) {
+                if (L.slab_stride > 0) P.colsum[(long long)lchunk_id * L.K + k] = v;
+                else atomicAdd(P.colsum + k, v);
+            }
+        }
+    }
+    if (do_colsum && !M32) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float v = csum[t];
@@ -1006,13 +1133,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
     const long long wrow = (long long)L.T * P.C;
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) {
+        if constexpr (M32) {                                // D: column = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int v = 0; v < 16; ++v)
+                    epi[(wk * 64 + kt * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)) * X3_EPI_LD + wc * 32 + (lane & 31)] = acc32[s3][kt][v];
+        } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    epi[(wk * 64 + i * 16 + fq * 4 + r) * X3_EPI_LD + wc * 32 + j * 16 + fr] = acc[s3][i][j][r];
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        epi[(wk * 64 + i * 16 + fq * 4 + r) * X3_EPI_LD + wc * 32 + j * 16 + fr] = acc[s3][i][j][r];
+        }
         __syncthreads();
         const long long coff = (long long)((P.r0 + kr * P.rs) * P.S + (P.s0 + s3 * P.ss)) * P.C + c0 + lane;
         if (L.wide) {
@@ -1280,13 +1415,19 @@ static int wgrad_launch(const Mi355ConvLaunch& in, float* const* dws, int64_t sl
             (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
             (void)hipFuncSetAttribute((const void*)conv_wgrad_row3x_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS);
             x3_attr = true;
         }
+        static const int m32_on = [] {                              // MI355_X3_M32=0: 16x16x32 MFMAs (A/B)
+            const char* e = getenv("MI355_X3_M32");
+            return e ? atoi(e) : 1;
+        }();
         const char* ae = getenv("MI355_X3_ABLATE");               // diagnostic builds (not cached: a bench tool sweeps it)
-        switch (ae ? atoi(ae) : 0) {
+        if (m32_on && (ae ? atoi(ae) : 0) == 0) hipLaunchKernelGGL((conv_wgrad_row3x_kernel<0, true>), g, dim3(512), X3_LDS, st, L);
+        else switch (ae ? atoi(ae) : 0) {
             case 1: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<1>, g, dim3(512), X3_LDS, st, L); break;
             case 2: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<2>, g, dim3(512), X3_LDS, st, L); break;
             case 3: hipLaunchKernelGGL(conv_wgrad_row3x_kernel<3>, g, dim3(512), X3_LDS, st, L); break;
