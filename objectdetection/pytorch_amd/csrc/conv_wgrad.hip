@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_row3_kernel(const WLaunch L
 //   block tile : kernel row r, 128 output channels, 128 input channels, the three column taps
 //   waves      : 2 (k) x 4 (c); a wave owns 64 k x 32 c x 3 taps = 96 accumulator VGPRs, as in the four-wave form
 //   stage      : 64 pixels: dy 64 x 128 k (16 KiB) + activation rows 72 x 128 c (18 KiB; 66 used, row 71 = zeros)
-//   LDS        : 3 stages (102 KiB) + a 1024-entry pixel-row ring (16 KiB, refilled 8 stages at a time)
+//   LDS        : 4 stages (136 KiB) + a 1024-entry pixel-row ring (8 KiB, refilled 8 stages at a time)
 // Both LDS images have 256-B rows with the 16-B chunk c at slot c ^ (f(row) << 1), f(row) = row & 3 | bit3(row) << 2:
 // the 8 rows of a 32-lane half of a transposed read (rows r0 .. r0 + 3 and r0 + 8 .. r0 + 11, any r0) then land in 8
 // distinct 32-B bank groups.  Widths dividing the 64-pixel stage only (fixed edge addresses); C % 128 == 0, K >= 128.
@@ -698,10 +698,19 @@ constexpr int X3_STAGE = X3_DY_BYTES + X3_XROWS * X3_TC * 2;    // 34 KiB
 constexpr int X3_NST = 4;                                   // ring depth: X3_NST - 1 stages in flight beside the one on the matrix cores
 constexpr int X3_TABN = 1024, X3_TAB_OFF = X3_NST * X3_STAGE;
 constexpr int X3_EPI_LD = X3_TC + 4;
-constexpr int X3_LDS = X3_TAB_OFF + X3_TABN * 16;
+constexpr int X3_LDS = X3_TAB_OFF + X3_TABN * 8;
 static_assert(TK * X3_EPI_LD * 4 <= X3_TAB_OFF, "epilogue staging must fit in the ring");
 
 typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ i2v lds_read8(unsigned addr) {
+    i2v v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_write8(unsigned addr, i2v v) {
+    asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
 typedef float f16v __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ i4v lds_read16(unsigned addr) {
     i4v v;
@@ -781,24 +790,25 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
     const int cx2 = c0 + ((slot ^ swz(xrow2)) << 3);
     const int xdelta = dh * P.W * P.C;
 
-    // pixel-row ring, entry (e + 1) & 1023 <-> pixel m_begin + e, e >= -1:
-    //   .x = element offset of input pixel (n, p, q)   .y = p (or far out of range)   .z = dy row offset / -1
+    // pixel-row ring, entry (e + 1) & 1023 <-> pixel m_begin + e, e >= -1: the two buffer offsets a DMA lane adds its own
+    // column to - .x = byte offset of input pixel (n, p + dh, q) (this block's kernel row folded in), .y = byte offset of
+    // the dy row; OOB_OFFSET where the row is padding / outside the chunk (OOB_OFFSET + a column offset stays out of range)
     const unsigned tab0 = lds0 + X3_TAB_OFF;
     auto fill = [&](int s0) {                           // entries of stages s0 .. s0 + 7 (e = 64 s0 - 1 .. 64 s0 + 512)
         for (int i = tid; i < 514; i += 512) {
             const int e = 64 * s0 + i - 1;
             const int m = m_begin + e;
-            i4v t = (i4v){0, -0x40000000, -1, 0};
+            i2v t = (i2v){(int)OOB_OFFSET, (int)OOB_OFFSET};
             if (m >= 0 && m < P.M) {
                 const unsigned n = fdiv((unsigned)m, P.dPQ);
                 const unsigned rem = (unsigned)m - n * (unsigned)(P.P * P.Q);
                 const unsigned p = fdiv(rem, P.dQ);
                 const unsigned q = rem - p * (unsigned)P.Q;
-                t.x = (int)n * P.in_sN + ((int)p * P.W + (int)q) * P.C;
-                t.y = (int)p;
-                if (m < m_end && e >= 0) t.z = (int)n * P.dy_sN + (int)rem * L.K;
+                if ((unsigned)((int)p + dh) < (unsigned)P.H)
+                    t.x = (int)((unsigned)((int)n * P.in_sN + ((int)p * P.W + (int)q) * P.C + xdelta) * 2u);
+                if (m < m_end && e >= 0) t.y = (int)((unsigned)((int)n * P.dy_sN + (int)rem * L.K) * 2u);
             }
-            lds_write16(tab0 + (unsigned)((e + 1) & (X3_TABN - 1)) * 16u, t);
+            lds_write8(tab0 + (unsigned)((e + 1) & (X3_TABN - 1)) * 8u, t);
         }
     };
     // DMA of one stage in two halves: `issue_prep` reads this thread's five pixel-row entries (LDS, asm) and leaves them
@@ -806,16 +816,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
     // wave-instruction.  The loop runs the prep beside the MFMAs in front of the stage barrier and spreads the pieces
     // over the MFMAs behind it: a burst of five pieces + their table reads is ~600 cycles in which neither this wave nor
     // - after a barrier: in the same phase - its SIMD partner issues an MFMA.
-    i4v tq[5];
+    i2v tq[5];
     unsigned doff[5];
     int dstep = 0;
     auto issue_prep = [&](int step) {
         const int eb = 64 * step;                       // ring index of dy row r: eb + r + 1; of activation row j: eb + j
 #pragma unroll
-        for (int i = 0; i < 2; ++i) tq[i] = lds_read16(tab0 + (unsigned)((eb + srow + 32 * i + 1) & (X3_TABN - 1)) * 16u);
+        for (int i = 0; i < 2; ++i) tq[i] = lds_read8(tab0 + (unsigned)((eb + srow + 32 * i + 1) & (X3_TABN - 1)) * 8u);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) tq[2 + i] = lds_read16(tab0 + (unsigned)((eb + srow + 32 * i) & (X3_TABN - 1)) * 16u);
-        tq[4] = lds_read16(tab0 + (unsigned)((eb + xrow2) & (X3_TABN - 1)) * 16u);
+        for (int i = 0; i < 2; ++i) tq[2 + i] = lds_read8(tab0 + (unsigned)((eb + srow + 32 * i) & (X3_TABN - 1)) * 8u);
+        tq[4] = lds_read8(tab0 + (unsigned)((eb + xrow2) & (X3_TABN - 1)) * 8u);
         dstep = step;
     };
     auto issue_offsets = [&]() {
@@ -825,11 +835,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_row3x_kernel(const WLaunch 
 #pragma unroll
         for (int i = 0; i < 5; ++i) asm volatile("" :: "v"(tq[i]));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) doff[i] = (ky_ok && tq[i].z >= 0) ? (unsigned)(tq[i].z + ky) * 2u : OOB_OFFSET;
+        for (int i = 0; i < 2; ++i) doff[i] = ky_ok ? (unsigned)tq[i].y + (unsigned)ky * 2u : OOB_OFFSET;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            doff[2 + i] = (unsigned)(tq[2 + i].y + dh) < (unsigned)P.H ? (unsigned)(tq[2 + i].x + xdelta + cx) * 2u : OOB_OFFSET;
-        doff[4] = (xrow2 < RM + 2 && (unsigned)(tq[4].y + dh) < (unsigned)P.H) ? (unsigned)(tq[4].x + xdelta + cx2) * 2u : OOB_OFFSET;
+        for (int i = 0; i < 2; ++i) doff[2 + i] = (unsigned)tq[2 + i].x + (unsigned)cx * 2u;
+        doff[4] = xrow2 < RM + 2 ? (unsigned)tq[4].x + (unsigned)cx2 * 2u : OOB_OFFSET;
     };
     auto issue_piece = [&](const int k) {               // k = 0, 1: dy; 2, 3: activation rows 0 .. 63; 4: rows 64 .. 71 (waves 0, 1)
         unsigned char* base = smem + (dstep % X3_NST) * X3_STAGE;
