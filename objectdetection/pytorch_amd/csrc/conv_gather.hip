@@ -282,9 +282,15 @@ __device__ __forceinline__ void gather_epilogue(f4v (&acc)[TA][4], const LaunchD
 //                   CU): everything else - HBM-bound 1x1 convs, layers with K <= 64, small launches.
 // (Measured and dropped this round: a 256x128 tile with a 3-stage counted-vmcnt ring at one block per CU and
 //  a 4-stage 128x128 ring - both slower than more resident blocks.)
-template <bool FLAT, int STAGES, int WM, int TA = 4, bool ST = false>
+// TAP1: every problem of the launch has at most one tap (the 1x1 convs of the bottlenecks, forward and data gradient -
+// a third of the R50 GPU time): the bounds test of a staged row does not change from k-step to k-step, so a thread keeps
+// its four A offsets and its B offsets final up to the channel block and a DMA piece costs one add with a scalar
+// instead of ~8 vector instructions (40 per k-step beside 16 MFMAs per wave: the SIMD's issue port, shared by up to five
+// resident waves, paced these launches).
+template <bool FLAT, int STAGES, int WM, int TA = 4, bool ST = false, bool TAP1 = false>
 __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(const LaunchDev L) {
     static_assert(TA == 4 || WM == 2, "narrow tile: 4 waves");
+    static_assert(!TAP1 || !FLAT, "single-tap form: channel-block k-steps");
     constexpr int NTHREADS = WM * 128, BM = WM * 64, BNT = TA == 4 ? 128 : 64;
     constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = A_BYTES + BNT * BK * 2;
     constexpr int NB = BNT * 8 / NTHREADS;            // B-tile DMA instructions per thread and stage
@@ -349,6 +355,16 @@ __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(
             b_rowoff[i] = nn < L.K ? (unsigned)(nn * wrow) * 2u : OOB_OFFSET;
         }
     }
+    if constexpr (TAP1) {                              // a_base / b_rowoff become the final byte offsets at channel block 0, or OOB
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = (unsigned)a_ih0[i] < (unsigned)P.H && (unsigned)a_iw0[i] < (unsigned)P.W;
+            a_base[i] = ok ? (int)((unsigned)(a_base[i] + kc * 8) * 2u) : (int)OOB_OFFSET;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (b_rowoff[i] != OOB_OFFSET) b_rowoff[i] += (unsigned)((P.r0 * P.S + P.s0) * P.C + kc * 8) * 2u;
+    }
     const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(P.in, (unsigned)P.in_bytes);
     const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(P.w, (unsigned)L.w_bytes);
 
@@ -371,6 +387,22 @@ __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(
     auto issue = [&](int ks, int buf) {
         unsigned char* sa = smem + buf * STAGE_BYTES;
         unsigned char* sb = sa + A_BYTES;
+        if constexpr (TAP1) {                               // (OOB_OFFSET + a channel offset stays out of range)
+            const unsigned cd = (unsigned)nx_c * 2u;       // wave-uniform
+            nx_c += BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (LDS_PTR(void))(sa + (i * NTHREADS + wv * 64) * 16),
+                                                         16, (unsigned)a_base[i] + cd, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                // (the offset through a named temporary: with `b_rowoff[i] + cd` as the argument the HOST pass of hipcc 7.2
+                //  drops this instantiation without a diagnostic and the library fails to load with an undefined stub)
+                const unsigned off = b_rowoff[i] + cd;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (LDS_PTR(void))(sb + (i * NTHREADS + wv * 64) * 16),
+                                                         16, off, 0, 0, 0);
+            }
+        } else {
         int ti, tj, c0;
         bool tap_ok = true;
         if (FLAT) {
@@ -406,6 +438,7 @@ __global__ __launch_bounds__(WM * 128, TA == 2 ? 4 : 2) void conv_gather_kernel(
             const unsigned off = (tap_ok && b_rowoff[i] != OOB_OFFSET) ? b_rowoff[i] + b_delta : OOB_OFFSET;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (LDS_PTR(void))(sb + (i * NTHREADS + wv * 64) * 16),
                                                      16, off, 0, 0, 0);
+        }
         }
     };
 
@@ -1270,6 +1303,7 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);
         (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NST);
         (void)hipFuncSetAttribute((const void*)conv_gather_kernel<true, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NST);
+        (void)hipFuncSetAttribute((const void*)conv_gather_kernel<false, 1, 2, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NST);
         (void)hipFuncSetAttribute((const void*)conv_gather_row3_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ROW3_A + 2 * ROW3_B);
         attr_set = true;
     }
@@ -1326,8 +1360,15 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
     }
     if (narrow) {
         if (single) {
-            if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2, 2>), g, b256, NST, st, L);
-            else      hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2, 2>), g, b256, NST, st, L);
+            static const int one_mode = [] {                // MI355_GATHER_ONE=0: the general staging for single-tap launches (A/B)
+                const char* e = getenv("MI355_GATHER_ONE");
+                return e ? atoi(e) : 1;
+            }();
+            bool one = one_mode != 0 && !flat;
+            for (int i = 0; i < in.nprob && one; ++i) one = in.prob[i].TR * in.prob[i].TS <= 1;
+            if (flat)     hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2, 2>), g, b256, NST, st, L);
+            else if (one) hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2, 2, false, true>), g, b256, NST, st, L);
+            else          hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2, 2>), g, b256, NST, st, L);
         } else {
             if (flat) hipLaunchKernelGGL((conv_gather_kernel<true, 2, 2, 2>), g, b256, 2 * NST, st, L);
             else      hipLaunchKernelGGL((conv_gather_kernel<false, 2, 2, 2>), g, b256, 2 * NST, st, L);
