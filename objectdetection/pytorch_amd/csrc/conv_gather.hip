@@ -515,7 +515,7 @@ __device__ __forceinline__ s8v lds_b128(unsigned addr) {
     return v;
 }
 
-template <bool ST = false>
+template <bool ST = false, bool TAP1 = false>          // TAP1: single-tap staging as in conv_gather_kernel
 __global__ __launch_bounds__(256, 2) void conv_gather_ring_kernel(const LaunchDev L) {
     constexpr int NTHREADS = 256, BM = 128, BNT = 64, TA = 2, RS = 3;
     constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = A_BYTES + BNT * BK * 2;      // 24 KiB
@@ -573,6 +573,16 @@ __global__ __launch_bounds__(256, 2) void conv_gather_ring_kernel(const LaunchDe
             b_rowoff[i] = nn < L.K ? (unsigned)(nn * wrow) * 2u : OOB_OFFSET;
         }
     }
+    if constexpr (TAP1) {                              // a_base / b_rowoff become the final byte offsets at channel block 0, or OOB
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = (unsigned)a_ih0[i] < (unsigned)P.H && (unsigned)a_iw0[i] < (unsigned)P.W;
+            a_base[i] = ok ? (int)((unsigned)(a_base[i] + kc * 8) * 2u) : (int)OOB_OFFSET;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (b_rowoff[i] != OOB_OFFSET) b_rowoff[i] += (unsigned)((P.r0 * P.S + P.s0) * P.C + kc * 8) * 2u;
+    }
     const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(P.in, (unsigned)P.in_bytes);
     const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(P.w, (unsigned)L.w_bytes);
     const int ksteps = P.TR * P.TS * (P.C / BK);
@@ -581,6 +591,23 @@ __global__ __launch_bounds__(256, 2) void conv_gather_ring_kernel(const LaunchDe
     auto issue = [&](int buf) {                          // k-steps are issued strictly in order
         unsigned char* sa = smem + buf * STAGE_BYTES;
         unsigned char* sb = sa + A_BYTES;
+        if constexpr (TAP1) {
+            const unsigned cd = (unsigned)nx_c * 2u;       // wave-uniform
+            nx_c += BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned off = (unsigned)a_base[i] + cd;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (LDS_PTR(void))(sa + (i * NTHREADS + wv * 64) * 16),
+                                                         16, off, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const unsigned off = b_rowoff[i] + cd;     // (named temporary: see conv_gather_kernel)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (LDS_PTR(void))(sb + (i * NTHREADS + wv * 64) * 16),
+                                                         16, off, 0, 0, 0);
+            }
+            return;
+        }
         const int ti = nx_ti, tj = nx_tj, c0 = nx_c + kc * 8;
         nx_c += BK;
         if (nx_c == P.C) {
@@ -1055,6 +1082,12 @@ static void pw_stream_launch(const PwStream& S, int lds, hipStream_t st) {
 
 }  // namespace
 
+// MI355_GATHER_ONE=0: the general staging for single-tap launches (A/B)
+static bool one_tap_mode() {
+    static const int on = [] { const char* e = getenv("MI355_GATHER_ONE"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
 static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void* stream);
 
 extern "C" int mi355_conv_gather(const Mi355ConvLaunch* launch, void* stream) {
@@ -1353,18 +1386,18 @@ static int gather_launch(const Mi355ConvLaunch& in, int ksplit, float* ws, void*
         static bool ring_attr = false;
         if (!ring_attr) {
             (void)hipFuncSetAttribute((const void*)conv_gather_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * NST);
+            (void)hipFuncSetAttribute((const void*)conv_gather_ring_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * NST);
             ring_attr = true;
         }
-        hipLaunchKernelGGL(conv_gather_ring_kernel<false>, g, b256, 3 * NST, st, L);
+        bool one1 = one_tap_mode();
+        for (int i = 0; i < in.nprob && one1; ++i) one1 = in.prob[i].TR * in.prob[i].TS <= 1;
+        if (one1) hipLaunchKernelGGL((conv_gather_ring_kernel<false, true>), g, b256, 3 * NST, st, L);
+        else      hipLaunchKernelGGL((conv_gather_ring_kernel<false, false>), g, b256, 3 * NST, st, L);
         return check_launch("conv_gather_ring_kernel");
     }
     if (narrow) {
         if (single) {
-            static const int one_mode = [] {                // MI355_GATHER_ONE=0: the general staging for single-tap launches (A/B)
-                const char* e = getenv("MI355_GATHER_ONE");
-                return e ? atoi(e) : 1;
-            }();
-            bool one = one_mode != 0 && !flat;
+            bool one = one_tap_mode() && !flat;
             for (int i = 0; i < in.nprob && one; ++i) one = in.prob[i].TR * in.prob[i].TS <= 1;
             if (flat)     hipLaunchKernelGGL((conv_gather_kernel<true, 1, 2, 2>), g, b256, NST, st, L);
             else if (one) hipLaunchKernelGGL((conv_gather_kernel<false, 1, 2, 2, false, true>), g, b256, NST, st, L);
